@@ -1,0 +1,155 @@
+"""ctypes front-end to the CPU checkers (TEST INFRASTRUCTURE -- see ssw_oracle.c header).
+
+Two interchangeable back-ends with the reference's four-call C interface
+(/root/reference/indelpost/ssw.h:86,91,126-134,139):
+
+* ``port``      -- oracle/libssw_oracle.so, this repo's scalar restatement (symbols ``orc_*``)
+* ``reference`` -- oracle/_ref/libssw_ref.so, the reference's ssw.c compiled unmodified from
+                   /root/reference by oracle/Makefile (absent on machines without that build)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_LIB = os.path.join(HERE, "libssw_oracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libssw_ref.so")
+
+
+class SAlign(C.Structure):
+    """s_align, ssw.h:55-66"""
+    _fields_ = [
+        ("score1", C.c_uint16), ("score2", C.c_uint16),
+        ("ref_begin1", C.c_int32), ("ref_end1", C.c_int32),
+        ("read_begin1", C.c_int32), ("read_end1", C.c_int32),
+        ("ref_end2", C.c_int32),
+        ("cigar", C.POINTER(C.c_uint32)), ("cigarLen", C.c_int32),
+        ("flag", C.c_uint16),
+    ]
+
+
+def build(force=False):
+    """(Re)build the checker libraries with oracle/Makefile (gcc only)."""
+    if force or not os.path.exists(PORT_LIB) or (
+            os.path.exists("/root/reference/indelpost/ssw.c") and not os.path.exists(REF_LIB)):
+        subprocess.check_call(["make", "-C", HERE, "-s", "all"])
+
+
+class Backend:
+    def __init__(self, kind="port"):
+        if kind == "reference":
+            path, pre = REF_LIB, ""
+        elif kind == "port":
+            path, pre = PORT_LIB, "orc_"
+        else:
+            raise ValueError(kind)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.kind, self.path, self.prefix = kind, path, pre
+        lib = C.CDLL(path)
+        self.lib = lib
+        self._init = getattr(lib, pre + "ssw_init")
+        self._init.restype = C.c_void_p
+        self._init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int8]
+        self._align = getattr(lib, pre + "ssw_align")
+        self._align.restype = C.POINTER(SAlign)
+        self._align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8,
+                                C.c_uint16, C.c_int32, C.c_int32]
+        self._adestroy = getattr(lib, pre + "align_destroy")
+        self._adestroy.argtypes = [C.POINTER(SAlign)]
+        self._adestroy.restype = None
+        self._idestroy = getattr(lib, pre + "init_destroy")
+        self._idestroy.argtypes = [C.c_void_p]
+        self._idestroy.restype = None
+
+    def align(self, read, ref, mat, gap_open, gap_ext, flag=1, filters=0, filterd=0, mask_len=None,
+              score_size=2):
+        """One ssw_init + ssw_align on int8 code arrays.  Returns a dict of the s_align fields
+        (cigar as a list of BAM-encoded uint32, or None when the C result has cigar==NULL)."""
+        read = np.ascontiguousarray(read, dtype=np.int8)
+        ref = np.ascontiguousarray(ref, dtype=np.int8)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        if mask_len is None:
+            mask_len = max(15, len(read) // 2)          # sswpy.pyx:209-211
+        # keep one spare byte so zero-length arrays still have a valid pointer
+        rd = np.concatenate([read, np.zeros(1, np.int8)])
+        rf = np.concatenate([np.zeros(1, np.int8), ref, np.zeros(1, np.int8)])
+        prof = self._init(rd.ctypes.data, len(read), mat.ctypes.data, 5, score_size)
+        res = self._align(prof, rf.ctypes.data + 1, len(ref), gap_open & 255, gap_ext & 255, flag,
+                          filters, filterd, mask_len)
+        if not res:
+            self._idestroy(prof)
+            return None
+        r = res.contents
+        out = dict(score1=r.score1, score2=r.score2, ref_begin1=r.ref_begin1, ref_end1=r.ref_end1,
+                   read_begin1=r.read_begin1, read_end1=r.read_end1, ref_end2=r.ref_end2,
+                   flag=r.flag,
+                   cigar=[int(r.cigar[k]) for k in range(r.cigarLen)] if r.cigar else None)
+        self._adestroy(res)
+        self._idestroy(prof)
+        return out
+
+    def cpu_baseline(self, reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mat, nthreads):
+        """Time the reference per-read loop on `nthreads` threads (cpu_baseline.c).
+        Returns (seconds, sum(score1), sum(cigarLen))."""
+        h = C.CDLL(PORT_LIB)
+        f = h.ipx_cpu_baseline
+        f.restype = C.c_int
+        f.argtypes = [C.c_char_p, C.c_char_p] + [C.c_void_p] * 8 + [C.c_int64, C.c_int,
+                                                                     C.POINTER(C.c_double),
+                                                                     C.POINTER(C.c_int64),
+                                                                     C.POINTER(C.c_int64)]
+        reads = np.ascontiguousarray(reads, np.int8)
+        read_off = np.ascontiguousarray(read_off, np.int64)
+        refs = np.ascontiguousarray(refs, np.int8)
+        ref_off = np.ascontiguousarray(ref_off, np.int64)
+        ref_id = np.ascontiguousarray(ref_id, np.int32)
+        go = np.ascontiguousarray(gap_open, np.uint8)
+        ge = np.ascontiguousarray(gap_ext, np.uint8)
+        mat = np.ascontiguousarray(mat, np.int8)
+        n = len(ref_id)
+        sec, chk, ops = C.c_double(), C.c_int64(), C.c_int64()
+        rc = f(self.path.encode(), self.prefix.encode(), reads.ctypes.data, read_off.ctypes.data,
+               refs.ctypes.data, ref_off.ctypes.data, ref_id.ctypes.data, go.ctypes.data,
+               ge.ctypes.data, mat.ctypes.data, n, nthreads, C.byref(sec), C.byref(chk), C.byref(ops))
+        if rc != 0:
+            raise RuntimeError("ipx_cpu_baseline failed: %d" % rc)
+        return sec.value, chk.value, ops.value
+
+
+def have_reference():
+    return os.path.exists(REF_LIB)
+
+
+def dna_matrix(match, mismatch):
+    """buildDNAScoreMatrix, sswpy.pyx:306-336 (args narrowed through uint8 then int8)."""
+    m = np.zeros((5, 5), np.int8)
+    ms = np.array([match & 255], np.uint8).astype(np.int8)[0]
+    mm = np.array([(-(mismatch & 255)) & 255], np.uint8).astype(np.int8)[0]
+    for i in range(4):
+        for j in range(4):
+            m[i, j] = ms if i == j else mm
+    return m.reshape(-1)
+
+
+_LUT = np.full(256, 4, np.int8)
+for _c, _v in (("A", 0), ("C", 1), ("G", 2), ("T", 3), ("U", 0)):
+    _LUT[ord(_c)] = _v
+    _LUT[ord(_c.lower())] = _v
+
+
+def encode(seq):
+    """DNA_BASE_LUT, sswpy.pyx:16-29."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    return _LUT[np.frombuffer(seq, np.uint8)]
+
+
+def cigar_string(cig):
+    if cig is None:
+        return None
+    return "".join("%d%s" % (c >> 4, "MIDNSHP=X"[c & 15] if (c & 15) <= 8 else "M") for c in cig)
