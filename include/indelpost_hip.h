@@ -1,0 +1,144 @@
+/*
+ * indelpost_hip.h -- C ABI of libindelpost_hip.so, the MI355X drop-in for indelPost's striped
+ * Smith-Waterman realignment path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Two layers:
+ *
+ *  (1) The reference's own FFI, symbol for symbol.  These are exactly the four functions
+ *      indelpost/sswpy.pyx binds (`cdef extern from "ssw.h"`, sswpy.pyx:57-83):
+ *          ssw_init      replaces ssw.h:86   / ssw.c:787-808
+ *          init_destroy  replaces ssw.h:91   / ssw.c:810-814
+ *          ssw_align     replaces ssw.h:126-134 / ssw.c:816-920
+ *          align_destroy replaces ssw.h:139  / ssw.c:922-925
+ *      Same signatures, same s_align layout (ssw.h:55-66), same ownership (result and cigar are
+ *      malloc'd by the callee and freed by align_destroy; the profile BORROWS read and mat,
+ *      ssw.c:803-804), same NULL-on-error convention (ssw.c:848-859).  Each call runs one
+ *      alignment on GPU 0 -- correct but latency-bound; it exists so the reference's binding links
+ *      unchanged.  The inline cigar helpers of ssw.h:171-190 are provided below under the same names.
+ *
+ *  (2) The batched entry points that the reference's per-read loop
+ *      (localn.pyx:47-66, 464-472 -> sswpy.pyx:149-178, 199-225) collapses into: a whole job table
+ *      (read, window id, gap_open, gap_extension) per call.  All buffers are caller-owned.
+ *
+ * Every function fails loudly (negative return / NULL + ipx_last_error()) when no GPU is present;
+ * there is no CPU fallback.
+ */
+#ifndef INDELPOST_HIP_H
+#define INDELPOST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) reference-compatible single-alignment interface
+ * ------------------------------------------------------------------------------------------- */
+struct _profile;
+typedef struct _profile s_profile;            /* ssw.h:36-37 */
+
+typedef struct {                              /* ssw.h:55-66 */
+    uint16_t score1;
+    uint16_t score2;
+    int32_t ref_begin1;
+    int32_t ref_end1;
+    int32_t read_begin1;
+    int32_t read_end1;
+    int32_t ref_end2;
+    uint32_t *cigar;
+    int32_t cigarLen;
+    uint16_t flag;
+} s_align;
+
+s_profile *ssw_init(const int8_t *read, const int32_t readLen, const int8_t *mat, const int32_t n,
+                    const int8_t score_size);
+void init_destroy(s_profile *p);
+s_align *ssw_align(const s_profile *prof, const int8_t *ref, int32_t refLen, const uint8_t weight_gapO,
+                   const uint8_t weight_gapE, const uint8_t flag, const uint16_t filters,
+                   const int32_t filterd, const int32_t maskLen);
+void align_destroy(s_align *a);
+
+#define IPX_MAPSTR "MIDNSHP=X"
+static inline char cigar_int_to_op(uint32_t cigar_int)      /* ssw.h:182-184 */
+{
+    return (cigar_int & 0xfU) > 8 ? 'M' : IPX_MAPSTR[cigar_int & 0xfU];
+}
+static inline uint32_t cigar_int_to_len(uint32_t cigar_int) /* ssw.h:190-192 */
+{
+    return cigar_int >> 4;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) batched interface
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ipx_ctx ipx_ctx;               /* one per GPU: stream, HBM-resident batch, workspace */
+
+/* One record per job: the fields of s_align with the cigar pointer replaced by (offset, length)
+ * into the caller's uint32 cigar pool (BAM encoding len<<4|op, M=0 I=1 D=2, ssw.h:171-173). 32 B. */
+typedef struct {
+    uint16_t score1;
+    uint16_t score2;
+    int32_t ref_begin1;
+    int32_t ref_end1;
+    int32_t read_begin1;
+    int32_t read_end1;
+    int32_t ref_end2;
+    uint32_t cigar_off;
+    uint16_t cigar_len;   /* 0: no cigar (reference: cigar == NULL) */
+    uint8_t flag;         /* s_align.flag: 0, 1 (traceback failed), 2 (path may miss a part) */
+    uint8_t mode;         /* 0: 8-bit pass result, 1: 16-bit pass result, 2: reference returns NULL */
+} ipx_result;
+
+enum {
+    IPX_OK = 0,
+    IPX_ERR_NO_DEVICE = -1,     /* no usable GPU / HIP runtime error: see ipx_last_error() */
+    IPX_ERR_ARG = -2,
+    IPX_ERR_READ_TOO_LONG = -3, /* a read needs segLen > 64 (reads > 512 bp in the 16-bit pass) */
+    IPX_ERR_REF_TOO_LONG = -4,  /* a window is longer than 4096 */
+    IPX_ERR_CIGAR_POOL = -5,    /* caller's cigar pool too small */
+    IPX_ERR_INTERNAL = -6
+};
+
+int ipx_device_count(void);
+ipx_ctx *ipx_create(int device);
+void ipx_destroy(ipx_ctx *c);
+const char *ipx_last_error(void);
+
+/* Scoring and ssw_align control arguments shared by the whole batch.
+ * mat: 5x5 row-major substitution matrix over A,C,G,T,N (sswpy.pyx:306-336);
+ * flag/filters/filterd: as ssw_align (ssw.c:821-823); score_size: as ssw_init (ssw.c:793-802). */
+int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int filterd, int score_size);
+
+/* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,
+ * ref_off: n_refs+1 offsets; ref_id[j]: window of job j; gap_open/gap_ext: already narrowed to
+ * uint8 (ssw.h:129-130); mask_len: per job, or NULL for max(15, readLen/2) (sswpy.pyx:209-211). */
+int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const int8_t *refs,
+               const int64_t *ref_off, const int32_t *ref_id, const uint8_t *gap_open,
+               const uint8_t *gap_ext, const int32_t *mask_len, int64_t n_jobs, int32_t n_refs);
+int ipx_run(ipx_ctx *c);                      /* enqueue the whole pipeline on the context's stream */
+int ipx_sync(ipx_ctx *c);                     /* wait; returns IPX_OK or the first error of the run */
+int ipx_download(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops);
+
+/* upload + run + sync + download in one call */
+int ipx_align_batch(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const int8_t *refs,
+                    const int64_t *ref_off, const int32_t *ref_id, const uint8_t *gap_open,
+                    const uint8_t *gap_ext, const int32_t *mask_len, int64_t n_jobs, int32_t n_refs,
+                    ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops);
+
+/* measurement: HIP events on the context's stream */
+int ipx_set_profiling(ipx_ctx *c, int on);
+int ipx_num_kernel_classes(void);
+const char *ipx_kernel_class_name(int k);
+int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches);   /* arrays of ipx_num_kernel_classes() */
+float ipx_last_run_ms(ipx_ctx *c);            /* events around the last ipx_run, valid after ipx_sync */
+
+/* deterministic synthetic workload of SURVEY.md section 8d (xorshift64), host side:
+ * one window of `wl` codes and n reads of `rl` codes; returns the final generator state */
+uint64_t ipx_synth_window(uint64_t state, int8_t *ref, int32_t wl);
+uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *reads, int64_t n, int32_t rl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

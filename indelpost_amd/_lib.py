@@ -1,0 +1,111 @@
+"""ctypes binding of libindelpost_hip.so (include/indelpost_hip.h).
+
+The library is built in-tree by :func:`build` (hipcc, gfx950 only).  Loading fails loudly when the
+shared object is missing; creating a context fails loudly when there is no GPU -- there is no CPU
+fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libindelpost_hip.so")
+SRC = os.path.join(PKG_DIR, "csrc", "ipx_runtime.hip")
+HEADERS = [os.path.join(PKG_DIR, "csrc", h) for h in
+           ("ipx_simt.h", "ipx_types.h", "ipx_kernels.h", "ipx_pipeline.h")] + [
+    os.path.join(os.path.dirname(PKG_DIR), "include", "indelpost_hip.h")]
+
+# numpy view of ipx_result (32 bytes)
+RESULT_DTYPE = np.dtype([
+    ("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"), ("ref_end1", "<i4"),
+    ("read_begin1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4"), ("cigar_off", "<u4"),
+    ("cigar_len", "<u2"), ("flag", "u1"), ("mode", "u1")])
+assert RESULT_DTYPE.itemsize == 32
+
+EXPORTS = [
+    # reference-compatible four-call interface (ssw.h:86,91,126-134,139)
+    "ssw_init", "init_destroy", "ssw_align", "align_destroy",
+    # batched interface
+    "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_upload",
+    "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch", "ipx_set_profiling",
+    "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_last_run_ms",
+    "ipx_synth_window", "ipx_synth_reads",
+]
+
+
+class IpxError(RuntimeError):
+    pass
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in [SRC] + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(LIB_PATH):
+            return LIB_PATH          # prebuilt library travelled with the tree
+        raise IpxError("hipcc not found and %s is not built" % LIB_PATH)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once) and declare the C signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IpxError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    L.ipx_device_count.restype = C.c_int
+    L.ipx_create.restype = vp
+    L.ipx_create.argtypes = [C.c_int]
+    L.ipx_destroy.argtypes = [vp]
+    L.ipx_destroy.restype = None
+    L.ipx_last_error.restype = C.c_char_p
+    L.ipx_set_params.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ipx_upload.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32]
+    L.ipx_run.argtypes = [vp]
+    L.ipx_sync.argtypes = [vp]
+    L.ipx_download.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
+    L.ipx_align_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, C.POINTER(i64)]
+    L.ipx_set_profiling.argtypes = [vp, C.c_int]
+    L.ipx_num_kernel_classes.restype = C.c_int
+    L.ipx_kernel_class_name.restype = C.c_char_p
+    L.ipx_kernel_class_name.argtypes = [C.c_int]
+    L.ipx_kernel_times.argtypes = [vp, vp, vp]
+    L.ipx_last_run_ms.restype = C.c_float
+    L.ipx_last_run_ms.argtypes = [vp]
+    L.ipx_synth_window.restype = C.c_uint64
+    L.ipx_synth_window.argtypes = [C.c_uint64, vp, i32]
+    L.ipx_synth_reads.restype = C.c_uint64
+    L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
+    for f in ("ipx_set_params", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch",
+              "ipx_set_profiling", "ipx_kernel_times"):
+        getattr(L, f).restype = C.c_int
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().ipx_last_error().decode(errors="replace")

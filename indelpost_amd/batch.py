@@ -1,0 +1,291 @@
+"""Batched striped Smith-Waterman on MI355X: job tables, GPU contexts, multi-GPU sharding.
+
+This is the batched counterpart of the reference's per-read loop
+``setRead -> ssw_init -> ssw_align -> align_destroy`` (indelpost/localn.py:464-472,
+indelpost/sswpy.pyx:149-178, 199-225): a *job* is (read, window id, gap_open, gap_extension); a
+batch of jobs is aligned by one call into libindelpost_hip.so.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import RESULT_DTYPE, IpxError
+
+_OPS = "MIDNSHP=X"
+
+# DNA_BASE_LUT of the reference (sswpy.pyx:16-25): A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, else 4.
+# Bytes >= 128 index the reference's table out of bounds (undefined); they map to N here.
+DNA_LUT = np.full(256, 4, np.int8)
+for _c, _v in (("A", 0), ("C", 1), ("G", 2), ("T", 3), ("U", 0)):
+    DNA_LUT[ord(_c)] = _v
+    DNA_LUT[ord(_c.lower())] = _v
+
+
+def encode_dna(seq):
+    """str/bytes -> int8 codes (dnaToInt8, sswpy.pyx:27-29)."""
+    if isinstance(seq, str):
+        seq = seq.encode("utf8")
+    return DNA_LUT[np.frombuffer(seq, np.uint8)]
+
+
+def dna_score_matrix(match_score, mismatch_penalty):
+    """5x5 int8 matrix of SSW.buildDNAScoreMatrix (sswpy.pyx:306-336): both arguments pass through
+    uint8 (sswpy.pyx:128-129) and are then stored as int8; the N row and column are 0."""
+    ms = np.array([int(match_score) & 255], np.uint8).astype(np.int8)[0]
+    mm = np.array([(-(int(mismatch_penalty) & 255)) & 255], np.uint8).astype(np.int8)[0]
+    m = np.zeros((5, 5), np.int8)
+    m[:4, :4] = mm
+    for i in range(4):
+        m[i, i] = ms
+    return m.reshape(-1)
+
+
+def cigar_to_string(ops):
+    """BAM-encoded uint32 ops -> '12M1D...' exactly as sswpy.pyx:283-289."""
+    return "".join("%d%s" % (int(c) >> 4, _OPS[int(c) & 15] if (int(c) & 15) <= 8 else "M") for c in ops)
+
+
+class JobTable:
+    """Concatenated reads/windows plus per-job window id and gap penalties (host, numpy)."""
+
+    def __init__(self, reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len=None):
+        self.reads = np.ascontiguousarray(reads, np.int8)
+        self.read_off = np.ascontiguousarray(read_off, np.int64)
+        self.refs = np.ascontiguousarray(refs, np.int8)
+        self.ref_off = np.ascontiguousarray(ref_off, np.int64)
+        self.ref_id = np.ascontiguousarray(ref_id, np.int32)
+        n = len(self.ref_id)
+        # Python ints narrow to uint8 at the C boundary (ssw.h:129-130)
+        self.gap_open = np.ascontiguousarray(np.broadcast_to(np.asarray(gap_open, np.int64) & 255, (n,)), np.uint8)
+        self.gap_ext = np.ascontiguousarray(np.broadcast_to(np.asarray(gap_ext, np.int64) & 255, (n,)), np.uint8)
+        self.mask_len = None if mask_len is None else np.ascontiguousarray(mask_len, np.int32)
+        if len(self.read_off) != n + 1:
+            raise ValueError("read_off must have n_jobs+1 entries")
+
+    @property
+    def n_jobs(self):
+        return len(self.ref_id)
+
+    @property
+    def n_refs(self):
+        return len(self.ref_off) - 1
+
+    @classmethod
+    def from_sequences(cls, reads, refs, ref_id, gap_open, gap_ext, encoded=False):
+        """reads / refs: lists of str/bytes (or int8 arrays when encoded=True)."""
+        enc = (lambda s: np.asarray(s, np.int8)) if encoded else encode_dna
+        r = [enc(s) for s in reads]
+        f = [enc(s) for s in refs]
+        ro = np.zeros(len(r) + 1, np.int64)
+        fo = np.zeros(len(f) + 1, np.int64)
+        if r:
+            ro[1:] = np.cumsum([len(x) for x in r])
+        if f:
+            fo[1:] = np.cumsum([len(x) for x in f])
+        rc = np.concatenate(r) if r and ro[-1] else np.zeros(0, np.int8)
+        fc = np.concatenate(f) if f and fo[-1] else np.zeros(0, np.int8)
+        return cls(rc, ro, fc, fo, ref_id, gap_open, gap_ext)
+
+    def shard(self, lo, hi):
+        """Contiguous job range [lo, hi) with only the windows it references."""
+        rid = self.ref_id[lo:hi]
+        used, inv = np.unique(rid, return_inverse=True)
+        lens = (self.ref_off[used + 1] - self.ref_off[used]) if len(used) else np.zeros(0, np.int64)
+        fo = np.zeros(len(used) + 1, np.int64)
+        fo[1:] = np.cumsum(lens)
+        refs = (np.concatenate([self.refs[self.ref_off[u]:self.ref_off[u + 1]] for u in used])
+                if len(used) and fo[-1] else np.zeros(0, np.int8))
+        base = self.read_off[lo]
+        return JobTable(self.reads[base:self.read_off[hi]], self.read_off[lo:hi + 1] - base, refs, fo,
+                        inv.astype(np.int32), self.gap_open[lo:hi], self.gap_ext[lo:hi],
+                        None if self.mask_len is None else self.mask_len[lo:hi])
+
+
+class BatchResult:
+    """Result records (numpy structured array, RESULT_DTYPE) + the cigar pool."""
+
+    def __init__(self, records, cigar_pool):
+        self.records = records
+        self.cigar_pool = cigar_pool
+
+    def __len__(self):
+        return len(self.records)
+
+    def cigar_ops(self, i):
+        r = self.records[i]
+        if r["cigar_len"] == 0:
+            return None
+        return self.cigar_pool[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["cigar_len"])]
+
+    def cigar_string(self, i):
+        ops = self.cigar_ops(i)
+        return None if ops is None else cigar_to_string(ops)
+
+    def as_dict(self, i):
+        """Same keys as oracle.Backend.align() for direct comparison in tests."""
+        r = self.records[i]
+        ops = self.cigar_ops(i)
+        return dict(score1=int(r["score1"]), score2=int(r["score2"]), ref_begin1=int(r["ref_begin1"]),
+                    ref_end1=int(r["ref_end1"]), read_begin1=int(r["read_begin1"]),
+                    read_end1=int(r["read_end1"]), ref_end2=int(r["ref_end2"]), flag=int(r["flag"]),
+                    cigar=None if ops is None else [int(x) for x in ops])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class GpuAligner:
+    """One GPU: HIP stream + HBM-resident batch + workspace (ipx_ctx)."""
+
+    def __init__(self, device=0, match_score=2, mismatch_penalty=2, matrix=None):
+        L = _lib.lib()
+        self._L = L
+        self._ctx = L.ipx_create(int(device))
+        if not self._ctx:
+            raise IpxError("ipx_create(%d) failed: %s" % (device, _lib.last_error()))
+        self.device = device
+        self._n_jobs = 0
+        self.set_scoring(match_score, mismatch_penalty, matrix)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.ipx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise IpxError("%s failed (%d): %s" % (what, rc, _lib.last_error()))
+
+    def set_scoring(self, match_score=2, mismatch_penalty=2, matrix=None, flag=1, filters=0, filterd=0,
+                    score_size=2):
+        m = dna_score_matrix(match_score, mismatch_penalty) if matrix is None else np.ascontiguousarray(matrix, np.int8)
+        if m.size != 25:
+            raise ValueError("matrix must be 5x5")
+        self.matrix = m
+        self._check(self._L.ipx_set_params(self._ctx, _p(m), flag, filters, filterd, score_size), "ipx_set_params")
+
+    # -- staged interface (bench.py: inputs resident in HBM before the timed region) --
+    def upload(self, jobs):
+        self._jobs = jobs   # keep host arrays alive
+        self._n_jobs = jobs.n_jobs
+        self._check(self._L.ipx_upload(self._ctx, _p(jobs.reads), _p(jobs.read_off), _p(jobs.refs), _p(jobs.ref_off),
+                                       _p(jobs.ref_id), _p(jobs.gap_open), _p(jobs.gap_ext), _p(jobs.mask_len),
+                                       jobs.n_jobs, jobs.n_refs), "ipx_upload")
+
+    def run(self):
+        self._check(self._L.ipx_run(self._ctx), "ipx_run")
+
+    def sync(self):
+        self._check(self._L.ipx_sync(self._ctx), "ipx_sync")
+
+    def download(self, cigar_ops_per_job=16):
+        n = self._n_jobs
+        rec = np.zeros(n, RESULT_DTYPE)
+        cap = max(1024, n * cigar_ops_per_job)
+        while True:
+            pool = np.zeros(cap, np.uint32)
+            used = C.c_int64(0)
+            rc = self._L.ipx_download(self._ctx, _p(rec), _p(pool), cap, C.byref(used))
+            if rc == -5 and used.value > cap:      # IPX_ERR_CIGAR_POOL: host pool too small
+                cap = int(used.value) + 16
+                continue
+            self._check(rc, "ipx_download")
+            return BatchResult(rec, pool[:used.value])
+
+    def align(self, jobs):
+        """upload + run + sync + download."""
+        self.upload(jobs)
+        for _ in range(6):
+            self.run()
+            rc = self._L.ipx_sync(self._ctx)
+            if rc == -5:                           # device cigar pool exhausted: let the C side grow it
+                return self._align_one_call(jobs)
+            self._check(rc, "ipx_sync")
+            break
+        return self.download()
+
+    def _align_one_call(self, jobs):
+        n = jobs.n_jobs
+        rec = np.zeros(n, RESULT_DTYPE)
+        cap = max(1024, n * 64)
+        while True:
+            pool = np.zeros(cap, np.uint32)
+            used = C.c_int64(0)
+            rc = self._L.ipx_align_batch(self._ctx, _p(jobs.reads), _p(jobs.read_off), _p(jobs.refs), _p(jobs.ref_off),
+                                         _p(jobs.ref_id), _p(jobs.gap_open), _p(jobs.gap_ext), _p(jobs.mask_len),
+                                         n, jobs.n_refs, _p(rec), _p(pool), cap, C.byref(used))
+            if rc == -5 and used.value > cap:
+                cap = int(used.value) + 16
+                continue
+            self._check(rc, "ipx_align_batch")
+            return BatchResult(rec, pool[:used.value])
+
+    # -- measurement --
+    def set_profiling(self, on):
+        self._check(self._L.ipx_set_profiling(self._ctx, 1 if on else 0), "ipx_set_profiling")
+
+    def kernel_times(self):
+        k = self._L.ipx_num_kernel_classes()
+        ms = np.zeros(k, np.float32)
+        cnt = np.zeros(k, np.int32)
+        self._check(self._L.ipx_kernel_times(self._ctx, _p(ms), _p(cnt)), "ipx_kernel_times")
+        return {self._L.ipx_kernel_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
+
+    def last_run_ms(self):
+        return float(self._L.ipx_last_run_ms(self._ctx))
+
+
+def device_count():
+    return int(_lib.lib().ipx_device_count())
+
+
+def shard_bounds(n_jobs, n_shards):
+    """Contiguous, near-equal job ranges: shard k owns [b[k], b[k+1])."""
+    return [n_jobs * k // n_shards for k in range(n_shards + 1)]
+
+
+def align_sharded(jobs, aligners):
+    """Split a job table over several GPUs (one host thread per GPU, no collective: every job is
+    independent) and gather the records back in job order."""
+    n = jobs.n_jobs
+    k = len(aligners)
+    b = shard_bounds(n, k)
+    parts = [None] * k
+    errs = []
+
+    def work(i):
+        try:
+            parts[i] = aligners[i].align(jobs.shard(b[i], b[i + 1]))
+        except Exception as e:      # surfaced to the caller below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return merge_results(parts)
+
+
+def merge_results(parts):
+    """Host-side gather: concatenate shard records, rebasing cigar offsets into one pool."""
+    recs, pools, base = [], [], 0
+    for p in parts:
+        r = p.records.copy()
+        r["cigar_off"] += np.uint32(base)
+        recs.append(r)
+        pools.append(p.cigar_pool)
+        base += len(p.cigar_pool)
+    return BatchResult(np.concatenate(recs) if recs else np.zeros(0, RESULT_DTYPE),
+                       np.concatenate(pools) if pools else np.zeros(0, np.uint32))

@@ -1,0 +1,646 @@
+// ipx_kernels.h -- the hot path of indelPost's local realignment as CDNA4 kernels.
+//
+// Replaces (all citations into /root/reference/indelpost/):
+//   k_dp_pass      <- sw_sse2_byte ssw.c:197-384 and sw_sse2_word ssw.c:410-586, forward and reverse,
+//                     including qP_byte/qP_word profile construction (ssw.c:163-188, 386-408) and
+//                     seq_reverse (ssw.c:774-785)
+//   k_traceback    <- banded_sw ssw.c:588-772
+//   k_plan_* / k_tb_list : the control flow of ssw_align (ssw.c:842-916), turned into device-side
+//                     job lists so that a whole batch runs without a host round trip
+//
+// Mapping of the SSE2 algorithm onto a 64-lane wavefront ("sub-wave groups"):
+//   * one SSE vector lane = one GPU lane.  The 8-bit pass (16 SSE lanes) uses one DPP row of 16
+//     lanes per read, the 16-bit pass (8 SSE lanes) uses half a row.  _mm_slli_si128 becomes
+//     `row_shr:1`, the horizontal max becomes 3-4 DPP butterfly steps.
+//   * every 32-bit VGPR holds TWO DP cells (v_pk_*_i16/u16): the low half belongs to the even
+//     alignment slot of the group, the high half to the odd slot.  A wave therefore carries 8 reads
+//     in the 8-bit pass and 16 reads in the 16-bit pass.  8-bit cells are computed in 16-bit
+//     containers (CDNA4 has no packed 8-bit saturating VALU); because the reference leaves the
+//     8-bit pass at the first column that reaches 255-bias (ssw.c:327) no value ever saturates
+//     before that column, so the un-saturated 16-bit result is bit-identical up to the exit.
+//   * the striped column state (H, E, and the column saved at the best score) lives in registers:
+//     segment j of the reference = register j, fully unrolled.
+//   * the substitution profile of the tile's reads is staged in LDS as int8 [letter][j][lane][half];
+//     per column each lane fetches its two profile bytes; the window bytes are streamed four
+//     columns at a time from 4-byte aligned, re-packed windows.
+//   * lazy-F keeps the reference's data-dependent exit per read: a read that would `goto end`
+//     gets its F zeroed, the wave leaves the loop when every read is out.
+#pragma once
+#include "ipx_simt.h"
+#include "ipx_types.h"
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+template <int W> IPX_DEV pk16 group_or(pk16 x)
+{
+    x |= xl_xor1(x);
+    x |= xl_xor2(x);
+    x |= xl_half_mirror(x);
+    if (W == 16) x |= xl_mirror(x);
+    return x;
+}
+template <int W> IPX_DEV pk16 group_max(pk16 x)
+{
+    x = pk_max(x, xl_xor1(x));
+    x = pk_max(x, xl_xor2(x));
+    x = pk_max(x, xl_half_mirror(x));
+    if (W == 16) x = pk_max(x, xl_mirror(x));
+    return x;
+}
+template <int W> IPX_DEV uint32_t group_umax(uint32_t x)
+{
+    uint32_t y;
+    y = xl_xor1(x); x = x > y ? x : y;
+    y = xl_xor2(x); x = x > y ? x : y;
+    y = xl_half_mirror(x); x = x > y ? x : y;
+    if (W == 16) { y = xl_mirror(x); x = x > y ? x : y; }
+    return x;
+}
+template <int W> IPX_DEV uint32_t group_umin(uint32_t x)
+{
+    uint32_t y;
+    y = xl_xor1(x); x = x < y ? x : y;
+    y = xl_xor2(x); x = x < y ? x : y;
+    y = xl_half_mirror(x); x = x < y ? x : y;
+    if (W == 16) { y = xl_mirror(x); x = x < y ? x : y; }
+    return x;
+}
+IPX_DEV uint32_t wave_umax(uint32_t x)
+{
+    for (int s = 1; s < 64; s <<= 1) { uint32_t y = xl_shfl(x, lane_id() ^ s); x = x > y ? x : y; }
+    return x;
+}
+IPX_DEV int mask_len_of(const IpxBatch &b, int64_t job, int readLen)
+{
+    if (b.mask_len) return b.mask_len[job];
+    int m = readLen / 2;
+    return m < 15 ? 15 : m;                                   // sswpy.pyx:209-211
+}
+IPX_DEV bool rev_needed(const IpxBatch &b, unsigned score1)   // ssw.c:872
+{
+    return !(b.flag == 0 || (b.flag == 2 && score1 < b.filters));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pack_refs: copy every window to a 4-byte aligned, padded slot; codes outside 0..4 become 4 (N)
+// ------------------------------------------------------------------------------------------------
+IPX_KERNEL void k_pack_refs(const int8_t *IPX_RESTRICT refs, const int64_t *IPX_RESTRICT ref_off,
+                            const int64_t *IPX_RESTRICT refp_off, int8_t *IPX_RESTRICT packed, int32_t n_refs)
+{
+    const int lane = lane_id();
+    const int waves_per_block = IPX_BDIM / 64;
+    for (int64_t r = (int64_t)IPX_BID * waves_per_block + IPX_TID / 64; r < n_refs;
+         r += (int64_t)IPX_GDIM * waves_per_block) {
+        const int64_t s = ref_off[r];
+        const int len = (int)(ref_off[r + 1] - s);
+        const int padded = ((len + 3) & ~3) + IPX_REF_PAD;
+        int8_t *dst = packed + refp_off[r];
+        for (int k = lane; k < padded; k += 64) {
+            int8_t c = 4;
+            if (k < len) { c = refs[s + k]; if ((uint8_t)c > 4) c = 4; }
+            dst[k] = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_init: result records start as "nothing aligned yet" (ssw.c:831-836)
+// ------------------------------------------------------------------------------------------------
+IPX_KERNEL void k_init(IpxBatch b)
+{
+    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
+        IpxResult r;
+        r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
+        r.ref_end2 = 0; r.cigar_off = 0; r.cigar_len = 0; r.flag = 0; r.mode = IPX_MODE_PENDING;
+        b.res[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// planner: which jobs take part in a pass, and in which segLen class
+// ------------------------------------------------------------------------------------------------
+// returns the class (segLen) of job i for `pass`, or -1 when the job does not take part
+IPX_DEV int plan_class(const IpxBatch &b, int pass, int64_t i)
+{
+    const int readLen = (int)(b.read_off[i + 1] - b.read_off[i]);
+    const int refLen = b.ref_len[b.ref_id[i]];
+    const IpxResult r = b.res[i];
+    int L, lanes, ncol;
+    switch (pass) {
+    case IPX_PASS_BYTE_FWD:
+        if (b.score_size == 1 || r.mode != IPX_MODE_PENDING) return -1;
+        L = readLen; lanes = 16; ncol = refLen;
+        break;
+    case IPX_PASS_WORD_FWD:
+        if (!((b.score_size == 1 && r.mode == IPX_MODE_PENDING) || r.mode == IPX_MODE_NEED_WORD)) return -1;
+        L = readLen; lanes = 8; ncol = refLen;
+        break;
+    case IPX_PASS_BYTE_REV:
+        if (r.mode != IPX_MODE_BYTE || !rev_needed(b, r.score1)) return -1;
+        L = r.read_end1 + 1; lanes = 16; ncol = r.ref_end1 + 1;
+        break;
+    default: // IPX_PASS_WORD_REV
+        if (r.mode != IPX_MODE_WORD || !rev_needed(b, r.score1)) return -1;
+        L = r.read_end1 + 1; lanes = 8; ncol = r.ref_end1 + 1;
+        break;
+    }
+    if (L < 0) L = 0;
+    const int cls = (L + lanes - 1) / lanes;
+    if (cls > IPX_MAX_SEG) { atomic_or_u32(b.status, IPX_STATUS_READ_TOO_LONG); return -1; }
+    if (ncol > IPX_MAX_REFLEN) { atomic_or_u32(b.status, IPX_STATUS_REF_TOO_LONG); return -1; }
+    return cls;
+}
+
+IPX_KERNEL void k_plan_zero(IpxPlan p)
+{
+    const int t = IPX_TID;
+    if (t < IPX_NUM_CLASSES) { p.count[t] = 0; p.cursor[t] = 0; }
+}
+
+IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
+{
+    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
+        const int cls = plan_class(b, pass, i);
+        if (cls >= 0) atomic_add_u32(&p.count[cls], 1u);
+    }
+}
+
+// one wave: exclusive scans over the 65 classes -> slot and tile offsets (NA = alignments per tile)
+IPX_KERNEL void k_plan_scan(IpxPlan p, int na)
+{
+    if (IPX_TID == 0) {
+        uint32_t so = 0, to = 0;
+        for (int c = 0; c < IPX_NUM_CLASSES; ++c) {
+            p.cls_off[c] = so;
+            p.tile_off[c] = to;
+            so += p.count[c];
+            to += (p.count[c] + (uint32_t)na - 1u) / (uint32_t)na;
+        }
+        p.cls_off[IPX_NUM_CLASSES] = so;
+        p.tile_off[IPX_NUM_CLASSES] = to;
+    }
+}
+
+IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
+{
+    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
+        const int cls = plan_class(b, pass, i);
+        if (cls >= 0) {
+            const uint32_t pos = atomic_add_u32(&p.cursor[cls], 1u);
+            p.perm[p.cls_off[cls] + pos] = (uint32_t)i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dp_pass: one striped Smith-Waterman pass over a tile of 128/W reads per wavefront
+//   W    = SSE lanes of the reference pass: 16 (8-bit semantics) or 8 (16-bit semantics)
+//   SMAX = largest segLen this instantiation holds in registers (tile's segLen S <= SMAX)
+//   REV  = reverse pass (reversed read prefix vs window prefix walked right to left, ssw.c:875-886)
+// Block = one wavefront (64 threads); grid-stride over the tiles of classes [cls_lo, cls_hi].
+// Dynamic LDS: profile 768*SMAX B | column maxima 4*G*maxcols B (forward only) | matrix 32 B
+// ------------------------------------------------------------------------------------------------
+template <int W, int SMAX, bool REV>
+IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols)
+{
+    constexpr int G = 64 / W;
+    constexpr int NA = 2 * G;
+    constexpr bool BYTE = (W == 16);
+    const int lane = lane_id();
+    const int g = lane / W, l = lane % W;
+    unsigned char *lds = IPX_LDS_BASE;
+    int8_t *prof = (int8_t *)lds;
+    uint32_t *maxcol = (uint32_t *)(lds + 768 * SMAX);
+    int8_t *matl = (int8_t *)(lds + 768 * SMAX + (REV ? 0 : 4 * G * maxcols));
+
+    if (lane < 25) matl[lane] = b.mat[lane];
+    IPX_SYNC();
+
+    const uint32_t tile_begin = p.tile_off[cls_lo], tile_end = p.tile_off[cls_hi + 1];
+    for (uint32_t tile = tile_begin + (uint32_t)IPX_BID; tile < tile_end; tile += (uint32_t)IPX_GDIM) {
+        // ---- locate the tile: class (= segLen), first slot in perm, number of reads -------------
+        int cls = cls_lo;
+        while (tile >= p.tile_off[cls + 1]) ++cls;
+        const int S = (int)xl_first((uint32_t)cls);
+        const uint32_t first = p.cls_off[cls] + (tile - p.tile_off[cls]) * NA;
+        const uint32_t avail = p.cls_off[cls + 1] - first;
+        const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
+
+        // ---- per-slot parameters (index 0 = low half, 1 = high half of every packed register) ----
+        int64_t job[2];
+        int L[2], ncol[2], tb[2], idx0[2], kmax[2], score1[2], rend1[2];
+        const int8_t *rd[2];
+        const uint32_t *refw[2];
+        int gO[2], gE[2];
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int slot = 2 * g + h;
+            job[h] = -1; L[h] = 0; ncol[h] = 0; tb[h] = 0; idx0[h] = 3; kmax[h] = 0; score1[h] = 0; rend1[h] = -1;
+            rd[h] = b.reads; refw[h] = (const uint32_t *)b.refs_packed; gO[h] = 0; gE[h] = 0;
+            if (slot < cnt) {
+                const int64_t jb = (int64_t)p.perm[first + slot];
+                const int rid = b.ref_id[jb];
+                const int refLen = b.ref_len[rid];
+                job[h] = jb;
+                rd[h] = b.reads + b.read_off[jb];
+                refw[h] = (const uint32_t *)(b.refs_packed + b.refp_off[rid]);
+                kmax[h] = ((refLen + 3) >> 2) + 1;
+                gO[h] = b.gap_open[jb];
+                gE[h] = b.gap_ext[jb];
+                if (!REV) {
+                    L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
+                    ncol[h] = refLen;
+                } else {
+                    const IpxResult r = b.res[jb];
+                    L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
+                    ncol[h] = r.ref_end1 + 1; if (ncol[h] < 0) ncol[h] = 0;
+                    score1[h] = r.score1;
+                    rend1[h] = r.read_end1;
+                    if (ncol[h] > 0) { idx0[h] = r.ref_end1 | 3; tb[h] = idx0[h] - r.ref_end1; }
+                }
+            }
+        }
+        const pk16 go = pk_make(gO[0], gO[1]), ge = pk_make(gE[0], gE[1]);
+        const pk16 term = pk_make(score1[0], score1[1]);
+        const pk16 capm1 = pk_splat(255 - b.bias - 1);          // overflow when colmax >= 255-bias (ssw.c:327)
+
+        // ---- stage the tile's query profile in LDS: int8 [6][S][64][2], row 5 = idle (zeros) -----
+        IPX_SYNC();   // previous tile's finalisation reads are done
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            for (int j = 0; j < S; ++j) {
+                const int r = j + l * S;                           // striped row (ssw.c:178-185)
+                int base = -1;
+                if (r < L[h]) {
+                    base = REV ? rd[h][L[h] - 1 - r] : rd[h][r];   // reverse pass: seq_reverse (ssw.c:774-785)
+                    if ((unsigned)base > 4u) base = 4;
+                }
+                for (int c = 0; c < 5; ++c)
+                    prof[((c * S + j) * 64 + lane) * 2 + h] = base >= 0 ? matl[c * 5 + base] : (int8_t)0;
+                prof[((5 * S + j) * 64 + lane) * 2 + h] = 0;
+            }
+        }
+        IPX_SYNC();
+
+        // ---- DP state -----------------------------------------------------------------------------
+        pk16 H[SMAX], E[SMAX], HM[SMAX];
+        IPX_UNROLL
+        for (int j = 0; j < SMAX; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
+        pk16 Hlast = 0, best = 0, done = 0, ovf = 0;
+        pk16 endref = BYTE ? 0xFFFFFFFFu : 0u;                      // ssw.c:220 / 427
+        const pk16 icol0 = REV ? pk_make(idx0[0], idx0[1]) : 0u;
+
+        const int T = (int)wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1])));
+        uint32_t cur[2], nxt[2];
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int k0 = REV ? (idx0[h] >> 2) : 0;
+            int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
+            if (k1 < 0) k1 = 0;
+            if (k1 > kmax[h]) k1 = kmax[h];
+            cur[h] = refw[h][k0 > kmax[h] ? kmax[h] : k0];
+            nxt[h] = refw[h][k1];
+        }
+
+        for (int t = 0; t < T; ++t) {
+            // -- window letters of this column, 4 columns per loaded dword ---------------------------
+            if ((t & 3) == 0 && t > 0) {
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    cur[h] = nxt[h];
+                    int k = REV ? (idx0[h] >> 2) - ((t >> 2) + 1) : (t >> 2) + 1;
+                    if (k < 0) k = 0;
+                    if (k > kmax[h]) k = kmax[h];
+                    nxt[h] = refw[h][k];
+                }
+            }
+            const uint32_t sh = (uint32_t)(REV ? 3 - (t & 3) : (t & 3)) * 8u;
+            uint32_t c[2];
+            pk16 act = 0;
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                const bool valid = (uint32_t)(t - tb[h]) < (uint32_t)ncol[h];
+                c[h] = valid ? ubfe(cur[h], sh, 8) : 5u;
+                if (valid) act |= (h ? 0xFFFF0000u : 0x0000FFFFu);
+            }
+            act &= ~done;
+            const pk16 icol = REV ? pk_sub(icol0, pk_splat(t)) : pk_splat(t);
+            const int8_t *pa0 = prof + ((int)c[0] * S * 64 + lane) * 2;
+            const int8_t *pa1 = prof + ((int)c[1] * S * 64 + lane) * 2 + 1;
+
+            // -- striped inner loop (ssw.c:274-299 / 480-504) -----------------------------------------
+            pk16 vH = xl_row_shr1(Hlast);                         // _mm_slli_si128(pvHStore[segLen-1], 1|2)
+            if (W == 8 && l == 0) vH = 0;
+            pk16 vF = 0, cmx = 0;
+            IPX_UNROLL
+            for (int j = 0; j < SMAX; ++j) {
+                if (j < S) {
+                    const pk16 pp = pk_make(pa0[j * 128], pa1[j * 128]);
+                    pk16 h = pk_add_sat(vH, pp);
+                    pk16 e = E[j];
+                    h = pk_max(h, e);
+                    h = pk_max(h, vF);
+                    cmx = pk_max(cmx, h);
+                    vH = H[j];
+                    H[j] = h;
+                    if (j == S - 1) Hlast = h;
+                    const pk16 tt = pk_subus(h, go);
+                    e = pk_subus(e, ge);
+                    E[j] = pk_max(e, tt);
+                    vF = pk_subus(vF, ge);
+                    vF = pk_max(vF, tt);
+                }
+            }
+
+            // -- lazy-F (ssw.c:302-313 / 507-518), per-read exit ---------------------------------------
+            for (int k = 0; k < W; ++k) {
+                vF = xl_row_shr1(vF);
+                if (W == 8 && l == 0) vF = 0;
+                if (!xl_any(vF != 0)) break;
+                bool fin = false;
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j) {
+                    if (j < S && !fin) {
+                        const pk16 h = pk_max(H[j], vF);
+                        cmx = pk_max(cmx, h);
+                        H[j] = h;
+                        if (j == S - 1) Hlast = h;
+                        const pk16 h2 = pk_subus(h, go);
+                        vF = pk_subus(vF, ge);
+                        // exit test: no lane with F > H-gapO; the 8-bit pass compares SIGNED bytes (ssw.c:311)
+                        const pk16 d = BYTE ? pk_subus(vF ^ 0x00800080u, h2 ^ 0x00800080u) : pk_subus(vF, h2);
+                        if (!xl_any(d != 0)) fin = true;
+                        else vF &= pk_nzmask(group_or<W>(d));      // reads that left the loop carry F = 0
+                    }
+                }
+                if (fin) break;
+            }
+
+            // -- column maximum, best score bookkeeping (ssw.c:316-337 / 521-539) ----------------------
+            const pk16 cmA = group_max<W>(cmx);
+            const pk16 om = BYTE ? (pk_nzmask(pk_subus(cmA, capm1)) & act) : 0u;  // 8-bit overflow: leave before recording
+            const pk16 a2 = act & ~om;
+            const pk16 nb = pk_max(best, cmA);
+            const pk16 m = pk_nzmask(pk_sub(nb, best)) & a2;                         // strictly better and still running
+            best = pk_select(m, nb, best);
+            endref = pk_select(m, icol, endref);
+            if (xl_any(m != 0)) {
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j)
+                    if (j < S) HM[j] = pk_select(m, H[j], HM[j]);                    // pvHmax (ssw.c:331 / 533)
+            }
+            if (!REV) { if (l == 0) maxcol[t * G + g] = cmA; }
+            ovf |= om;
+            done |= om;
+            if (REV) done |= (~pk_nzmask(cmA ^ term)) & a2;                          // maxColumn[i] == terminate
+            // -- anything left to do? ---------------------------------------------------------------
+            bool alive = false;
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h)
+                alive = alive || ((t + 1 < tb[h] + ncol[h]) && ((done >> (16 * h)) & 0xFFFFu) == 0);
+            if (!xl_any(alive)) break;
+        }
+
+        // ---- finalisation ---------------------------------------------------------------------------
+        IPX_SYNC();   // column maxima written by lane 0 of each group are visible to the group
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            // end position on the read: smallest striped row holding `best` in the saved column (ssw.c:340-349)
+            const unsigned bh = (best >> (16 * h)) & 0xFFFFu;
+            uint32_t rmin = 0x7FFFFFFFu;
+            IPX_UNROLL
+            for (int j = SMAX - 1; j >= 0; --j)
+                if (j < S && (((HM[j] >> (16 * h)) & 0xFFFFu) == bh)) rmin = (uint32_t)(j + l * S);
+            rmin = group_umin<W>(rmin);
+            int end_read = L[h] - 1;
+            if ((int)rmin < end_read) end_read = (int)rmin;
+            const int eref = (int)(int16_t)((endref >> (16 * h)) & 0xFFFFu);
+            const bool overflow = ((ovf >> (16 * h)) & 0xFFFFu) != 0;
+
+            if (!REV) {
+                // second best outside the mask window (ssw.c:366-379 / 568-581)
+                const int refLen = ncol[h];
+                const int maskLen = job[h] >= 0 ? mask_len_of(b, job[h], L[h]) : 15;
+                int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
+                int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
+                if (BYTE) edgeR += 1;
+                uint32_t key = 0xFFFFu;                               // (score2 = 0, ref_end2 = 0)
+                for (int col = l; col < refLen; col += W) {
+                    if (col < edgeL || col >= edgeR) {
+                        const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
+                        const uint32_t kk = (v << 16) | (0xFFFFu - (uint32_t)col);
+                        if (v > (key >> 16)) key = kk;
+                    }
+                }
+                key = group_umax<W>(key);
+                if (l == 0 && job[h] >= 0) {
+                    IpxResult r = b.res[job[h]];
+                    if (BYTE && overflow) {
+                        if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }                 // -> 16-bit pass (ssw.c:844-847)
+                        else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851
+                    } else {
+                        r.mode = BYTE ? IPX_MODE_BYTE : IPX_MODE_WORD;
+                        r.score1 = (uint16_t)bh;
+                        r.ref_end1 = eref;
+                        r.read_end1 = end_read;
+                        r.read_begin1 = -1;
+                        if (maskLen >= 15) { r.score2 = (uint16_t)(key >> 16); r.ref_end2 = (int)(0xFFFFu - (key & 0xFFFFu)); }
+                        else { r.score2 = 0; r.ref_end2 = -1; }                                                // ssw.c:864-870
+                    }
+                    b.res[job[h]] = r;
+                }
+            } else {
+                if (l == 0 && job[h] >= 0) {
+                    IpxResult r = b.res[job[h]];
+                    const unsigned best_rev = (BYTE && overflow) ? 255u : bh;
+                    r.ref_begin1 = eref;                                                                       // ssw.c:885
+                    r.read_begin1 = rend1[h] - end_read;                                                       // ssw.c:886
+                    if ((unsigned)score1[h] > best_rev) r.flag = 2;                                            // ssw.c:888-891
+                    b.res[job[h]] = r;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// traceback job list: jobs that get a CIGAR (ssw.c:894)
+// ------------------------------------------------------------------------------------------------
+IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
+{
+    if (r.mode != IPX_MODE_BYTE && r.mode != IPX_MODE_WORD) return false;
+    if (!rev_needed(b, r.score1)) return false;
+    if ((7 & b.flag) == 0) return false;
+    if ((2 & b.flag) != 0 && r.score1 < b.filters) return false;
+    if ((4 & b.flag) != 0 && (r.ref_end1 - r.ref_begin1 > b.filterd || r.read_end1 - r.read_begin1 > b.filterd)) return false;
+    return true;
+}
+
+IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *list, uint32_t *list_n)
+{
+    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
+        if (cigar_needed(b, b.res[i])) list[atomic_add_u32(list_n, 1u)] = (uint32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_traceback: banded affine DP + traceback -> BAM-encoded CIGAR (banded_sw, ssw.c:588-772)
+// One lane per job.  Per-lane scratch (interleaved [slot][lane] so a wave's accesses coalesce):
+//   hb/eb/hc : int32 band rows          (arrcap slots each)
+//   dir      : 1 byte per DP cell       (dircap cells): bit7 written | bits3:2 H source (0 diag,
+//              1 E, 2 F) | bit1 F came from open | bit0 E came from open -- the reference's three
+//              direction planes of a cell, kept at the reference's linear cell index so that
+//              out-of-band reads alias the same cells; never-written cells read 0 = the
+//              reference's "Trace back error" path (it reads uninitialised heap there)
+//   cig      : uint32 ops, reversed     (cigcap)
+// Jobs whose band outgrows the scratch are appended to `next` for a launch with more scratch.
+// ------------------------------------------------------------------------------------------------
+struct IpxTbScratch {
+    int32_t *hb, *eb, *hc;
+    uint8_t *dir;
+    uint32_t *cig;
+    int32_t arrcap, dircap, cigcap;
+};
+
+IPX_KERNEL_WAVE void k_traceback(IpxBatch b, const uint32_t *list, const uint32_t *list_n, IpxTbScratch s,
+                            uint32_t *next, uint32_t *next_n)
+{
+    const int lane = lane_id();
+    int8_t *matl = (int8_t *)IPX_LDS_BASE;
+    if (IPX_TID < 25) matl[IPX_TID] = b.mat[IPX_TID];
+    IPX_SYNC();
+    const int waves_per_block = IPX_BDIM / 64;
+    const int64_t wslot = (int64_t)IPX_BID * waves_per_block + IPX_TID / 64;   // scratch slot of this wave
+    int32_t *hb = s.hb + wslot * (int64_t)s.arrcap * 64 + lane;
+    int32_t *eb = s.eb + wslot * (int64_t)s.arrcap * 64 + lane;
+    int32_t *hc = s.hc + wslot * (int64_t)s.arrcap * 64 + lane;
+    uint8_t *dir = s.dir + wslot * (int64_t)s.dircap * 64 + lane;
+    uint32_t *cig = s.cig + wslot * (int64_t)s.cigcap * 64 + lane;
+    const uint32_t n = *list_n;
+    const int64_t nwaves = (int64_t)IPX_GDIM * waves_per_block;
+
+    for (int64_t base = wslot * 64; base < (int64_t)n; base += nwaves * 64) {
+        const int64_t li = base + lane;
+        if (li >= (int64_t)n) continue;
+        const int64_t jb = list[li];
+        IpxResult r = b.res[jb];
+        const int rid = b.ref_id[jb];
+        const int fullRef = b.ref_len[rid];
+        const int8_t *refp = b.refs_packed + b.refp_off[rid];
+        const int8_t *readp = b.reads + b.read_off[jb] + r.read_begin1;
+        const int rb = r.ref_begin1;
+        const int refLen = r.ref_end1 - r.ref_begin1 + 1;             // ssw.c:897-899
+        const int readLen = r.read_end1 - r.read_begin1 + 1;
+        const int gapO = b.gap_open[jb], gapE = b.gap_ext[jb];
+        const int score = r.score1;
+        int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+        const int len = refLen > readLen ? refLen : readLen;
+        int mx = 0, width = 0, width_d = 0, cap = 0, extent = 0;
+        bool escalate = false;
+
+        do {
+            width = bw * 2 + 3;
+            width_d = bw * 2 + 1;
+            const int64_t cells = (int64_t)width_d * (readLen > 0 ? readLen : 1);
+            if (width + 1 > s.arrcap || cells > (int64_t)s.dircap) { escalate = true; break; }
+            for (int q = cap; q < width + 1; ++q) { hb[q * 64] = 0; eb[q * 64] = 0; hc[q * 64] = 0; }
+            if (width + 1 > cap) cap = width + 1;
+            for (int q = extent; q < (int)cells; ++q) dir[(int64_t)q * 64] = 0;
+            if ((int)cells > extent) extent = (int)cells;
+            for (int j = 1; j < width - 1; ++j) hb[j * 64] = 0;                          // ssw.c:627
+            for (int i = 0; i < readLen; ++i) {
+                int beg = 0, end = refLen - 1, u = 0;
+                if (i - bw > beg) beg = i - bw;
+                if (i + bw < end) end = i + bw;
+                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;                // ssw.c:632
+                int f = 0;
+                hb[0] = 0; eb[0] = 0; hb[edge * 64] = 0; eb[edge * 64] = 0; hc[0] = 0;     // ssw.c:633
+                const int x = i - bw > 0 ? i - bw : 0;                                   // band shift of row i
+                const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;                          // ... of row i-1
+                int rc = readp[i];
+                if ((unsigned)rc > 4u) rc = 4;
+                int hleft = 0;                                                             // h_c[b]: cell to the left
+                for (int j = beg; j <= end; ++j) {
+                    u = j - x + 1;                                                         // set_u (ssw.c:92)
+                    const int e = j - xp + 1;
+                    const int d = j - 1 - xp + 1;
+                    int t1 = i == 0 ? -gapO : hb[e * 64] - gapO;                           // ssw.c:644-648
+                    int t2 = i == 0 ? -gapE : eb[e * 64] - gapE;
+                    const int ev = t1 > t2 ? t1 : t2;
+                    const int de = t1 > t2 ? 1 : 0;
+                    eb[u * 64] = ev;
+                    t1 = hleft - gapO;                                                     // ssw.c:650-653 (h_c[0] = 0 at the band's left edge)
+                    t2 = f - gapE;
+                    f = t1 > t2 ? t1 : t2;
+                    const int df = t1 > t2 ? 1 : 0;
+                    const int e1 = ev > 0 ? ev : 0;                                        // ssw.c:655-664
+                    const int f1 = f > 0 ? f : 0;
+                    t1 = e1 > f1 ? e1 : f1;
+                    const int ri = rb + j;
+                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    t2 = hb[d * 64] + matl[rcode * 5 + rc];
+                    const int hv = t1 > t2 ? t1 : t2;
+                    hc[u * 64] = hv;
+                    hleft = hv;
+                    if (hv > mx) mx = hv;
+                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
+                    dir[((int64_t)width_d * i + (j - x)) * 64] = (uint8_t)(0x80 | (dh << 2) | (df << 1) | de);
+                }
+                for (int j = 1; j <= u; ++j) hb[j * 64] = hc[j * 64];                       // ssw.c:666
+            }
+            bw *= 2;
+        } while (mx < score && bw <= len);                                                // ssw.c:669
+        if (escalate) {
+            if (next) next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb;
+            else atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH);
+            continue;
+        }
+        bw /= 2;
+
+        // ---- trace back (ssw.c:673-751) ----
+        int i = readLen - 1, j = refLen - 1, e = 0, lcnt = 0, plane = 2;
+        int op = 0, prev = 0;                                   // 0 M, 1 I, 2 D
+        bool fail = false, full = false;
+        while (i >= 0 && j > 0) {
+            const int x = i - bw > 0 ? i - bw : 0;
+            const int64_t cell = (int64_t)width_d * i + (j - x);
+            int code = 0;
+            if (cell >= 0 && cell < extent) {
+                const int v = dir[cell * 64];
+                if (v & 0x80) {
+                    const int de = 2 + (v & 1), df = 4 + ((v >> 1) & 1), dh = (v >> 2) & 3;
+                    code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
+                }
+            }
+            if (code == 1) { --i; --j; plane = 2; op = 0; }
+            else if (code == 2) { --i; plane = 0; op = 1; }
+            else if (code == 3) { --i; plane = 2; op = 1; }
+            else if (code == 4) { --j; plane = 1; op = 2; }
+            else if (code == 5) { --j; plane = 2; op = 2; }
+            else { fail = true; break; }
+            if (op == prev) ++e;
+            else {
+                ++lcnt;
+                if (lcnt + 2 > s.cigcap) { full = true; break; }
+                cig[(lcnt - 1) * 64] = ((uint32_t)e << 4) | (uint32_t)prev;
+                prev = op;
+                e = 1;
+            }
+        }
+        if (full) {
+            if (next) next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb;
+            else atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH);
+            continue;
+        }
+        if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; continue; }                // ssw.c:911
+        if (op == 0) { ++lcnt; cig[(lcnt - 1) * 64] = ((uint32_t)(e + 1) << 4); }          // ssw.c:734-751
+        else { lcnt += 2; cig[(lcnt - 2) * 64] = ((uint32_t)e << 4) | (uint32_t)op; cig[(lcnt - 1) * 64] = (1u << 4); }
+        const uint32_t off = atomic_add_u32(b.cigar_cursor, (uint32_t)lcnt);
+        if (off + (uint32_t)lcnt > b.cigar_cap) { atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL); continue; }
+        for (int k = 0; k < lcnt; ++k) b.cigar_pool[off + k] = cig[(lcnt - 1 - k) * 64];   // reverse (ssw.c:754-762)
+        r.cigar_off = off;
+        r.cigar_len = (uint16_t)lcnt;
+        b.res[jb] = r;
+    }
+}

@@ -1,0 +1,517 @@
+// ipx_runtime.hip -- host side of libindelpost_hip.so: HIP memory/stream plumbing and the C ABI of
+// include/indelpost_hip.h.  HIP runtime only (no PyTorch, no vendor libraries).  Every entry
+// point fails loudly when there is no GPU; nothing here computes an alignment on the CPU.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/indelpost_hip.h"
+#include "ipx_pipeline.h"
+
+static_assert(sizeof(IpxResult) == 32 && sizeof(ipx_result) == 32, "result record is 32 bytes");
+
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return IPX_ERR_NO_DEVICE;                                                       \
+        }                                                                                   \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { set_err("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return IPX_ERR_NO_DEVICE; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct ipx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    // parameters
+    int8_t mat[25];
+    int bias = 0, flag = 1, filters = 0, filterd = 0, score_size = 2;
+    // resident batch
+    int64_t n_jobs = 0;
+    int32_t n_refs = 0;
+    IpxDims dims = {0, 0};
+    bool have_mask = false;
+    DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
+    DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
+    DevBuf perm, tb_list, tb_next, tb0, tb1;
+    uint32_t cigar_cap = 0;
+    IpxWorkspace ws;
+    IpxBatch batch;
+    // measurement
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_used;   // (kernel class, index of start event; stop = +1)
+    size_t ev_next = 0;
+    float k_ms[IPX_K_NUM];
+    int k_launches[IPX_K_NUM];
+    hipEvent_t run_start = nullptr, run_stop = nullptr;
+    float last_run_ms = 0.f;
+    std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
+};
+
+// ---- launcher handed to ipx_run_pipeline --------------------------------------------------------
+struct HipBackend {
+    ipx_ctx *c;
+    hipError_t err = hipSuccess;
+    int dp_grid() const
+    {
+        int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
+        const int64_t cap = (int64_t)c->num_cu * 16;
+        return (int)(g < cap ? g : cap);
+    }
+    int flat_grid(int64_t n) const
+    {
+        int64_t g = (n + 255) / 256;
+        if (g < 1) g = 1;
+        const int64_t cap = (int64_t)c->num_cu * 8;
+        return (int)(g < cap ? g : cap);
+    }
+    void zero_u32(uint32_t *p, int n)
+    {
+        hipError_t e = hipMemsetAsync(p, 0, sizeof(uint32_t) * (size_t)n, c->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    }
+    template <class K, class... A>
+    void launch(int kclass, K kern, int grid, int block, int lds, A... args)
+    {
+        if (lds > 48 * 1024) {
+            const void *key = (const void *)kern;
+            auto it = c->lds_attr.find(key);
+            if (it == c->lds_attr.end() || it->second < lds) {
+                hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess && err == hipSuccess) err = e;
+                c->lds_attr[key] = lds;
+            }
+        }
+        size_t ei = 0;
+        if (c->profiling) {
+            if (c->ev_next + 2 > c->ev_pool.size()) {
+                for (int k = 0; k < 64; ++k) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+            }
+            ei = c->ev_next;
+            c->ev_next += 2;
+            (void)hipEventRecord(c->ev_pool[ei], c->stream);
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), (size_t)lds, c->stream, args...);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        if (c->profiling) {
+            (void)hipEventRecord(c->ev_pool[ei + 1], c->stream);
+            c->ev_used.push_back(std::make_pair(kclass, (int)ei));
+        }
+    }
+};
+
+static const char *k_names[IPX_K_NUM] = {"init", "plan", "dp_byte_fwd", "dp_word_fwd", "dp_byte_rev",
+                                         "dp_word_rev", "tb_list", "traceback", "pack_refs"};
+
+extern "C" {
+
+const char *ipx_last_error(void) { return g_err; }
+
+int ipx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+ipx_ctx *ipx_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_err("no HIP device available (%s): libindelpost_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0"); return nullptr; }
+    if (device < 0 || device >= n) { set_err("device %d out of range (0..%d)", device, n - 1); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
+    ipx_ctx *c = new ipx_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete c; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    (void)hipEventCreate(&c->run_start);
+    (void)hipEventCreate(&c->run_stop);
+    memset(c->k_ms, 0, sizeof c->k_ms);
+    memset(c->k_launches, 0, sizeof c->k_launches);
+    // default scoring: SSW() class defaults, match 2 / mismatch 2 (sswpy.pyx:112)
+    static const int8_t dflt[25] = {2, -2, -2, -2, 0, -2, 2, -2, -2, 0, -2, -2, 2, -2, 0, -2, -2, -2, 2, 0, 0, 0, 0, 0, 0};
+    memcpy(c->mat, dflt, 25);
+    c->bias = 2;
+    memset(&c->ws, 0, sizeof c->ws);
+    memset(&c->batch, 0, sizeof c->batch);
+    return c;
+}
+
+void ipx_destroy(ipx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
+                      &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
+                      &c->tb_list, &c->tb_next, &c->tb0, &c->tb1})
+        b->release();
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->run_start);
+    (void)hipEventDestroy(c->run_stop);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int filterd, int score_size)
+{
+    if (!c || !mat || score_size < 0 || score_size > 2) { set_err("ipx_set_params: bad argument"); return IPX_ERR_ARG; }
+    memcpy(c->mat, mat, 25);
+    int bias = 0;
+    for (int k = 0; k < 25; ++k) if (mat[k] < bias) bias = mat[k];          // ssw.c:795-797
+    c->bias = -bias;
+    c->flag = flag & 255; c->filters = filters & 0xFFFF; c->filterd = filterd; c->score_size = score_size;
+    return IPX_OK;
+}
+
+static int carve_tb(ipx_ctx *c, DevBuf &buf, const IpxTbSizing &s, int waves, IpxTbScratch *out)
+{
+    const size_t per = ipx_tb_bytes_per_wave(s);
+    if (buf.ensure(per * (size_t)waves)) return IPX_ERR_NO_DEVICE;
+    char *p = buf.as<char>();
+    const size_t arr = 64ull * 4ull * (size_t)s.arrcap * (size_t)waves;
+    out->hb = (int32_t *)p; p += arr;
+    out->eb = (int32_t *)p; p += arr;
+    out->hc = (int32_t *)p; p += arr;
+    out->cig = (uint32_t *)p; p += 64ull * 4ull * (size_t)s.cigcap * (size_t)waves;
+    out->dir = (uint8_t *)p;
+    out->arrcap = s.arrcap; out->dircap = s.dircap; out->cigcap = s.cigcap;
+    return 0;
+}
+
+int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const int8_t *refs,
+               const int64_t *ref_off, const int32_t *ref_id, const uint8_t *gap_open,
+               const uint8_t *gap_ext, const int32_t *mask_len, int64_t n_jobs, int32_t n_refs)
+{
+    if (!c || n_jobs < 0 || n_refs < 0 || !read_off || !ref_off || (n_jobs > 0 && (!ref_id || !gap_open || !gap_ext))) {
+        set_err("ipx_upload: bad argument");
+        return IPX_ERR_ARG;
+    }
+    if (n_jobs >= (1ll << 31)) { set_err("ipx_upload: more than 2^31 jobs in one batch"); return IPX_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t read_bytes = read_off[n_jobs], ref_bytes = ref_off[n_refs];
+    // host-side geometry: packed (4-byte aligned, padded) window offsets and the batch maxima
+    std::vector<int64_t> refp((size_t)n_refs + 1);
+    std::vector<int32_t> rlen((size_t)n_refs + 1);
+    IpxDims d = {0, 0};
+    int64_t tot = 0;
+    for (int32_t r = 0; r < n_refs; ++r) {
+        const int64_t len = ref_off[r + 1] - ref_off[r];
+        if (len < 0 || len > IPX_MAX_REFLEN) { set_err("window %d has length %lld (limit %d)", r, (long long)len, IPX_MAX_REFLEN); return IPX_ERR_REF_TOO_LONG; }
+        refp[r] = tot; rlen[r] = (int32_t)len;
+        tot += ((len + 3) & ~3ll) + IPX_REF_PAD;
+        if (len > d.max_ref_len) d.max_ref_len = (int)len;
+    }
+    for (int64_t i = 0; i < n_jobs; ++i) {
+        const int64_t len = read_off[i + 1] - read_off[i];
+        if (len < 0 || len > 8 * IPX_MAX_SEG) { set_err("read %lld has length %lld (limit %d)", (long long)i, (long long)len, 8 * IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
+        if (len > d.max_read_len) d.max_read_len = (int)len;
+        if (ref_id[i] < 0 || ref_id[i] >= n_refs) { set_err("job %lld: ref_id %d out of range", (long long)i, ref_id[i]); return IPX_ERR_ARG; }
+    }
+    c->n_jobs = n_jobs; c->n_refs = n_refs; c->dims = d; c->have_mask = mask_len != nullptr;
+
+    if (c->reads.ensure((size_t)read_bytes + 64) || c->read_off.ensure(8 * ((size_t)n_jobs + 1)) ||
+        c->refs_raw.ensure((size_t)ref_bytes + 64) || c->ref_off.ensure(8 * ((size_t)n_refs + 1)) ||
+        c->refs_packed.ensure((size_t)tot + 64) || c->refp_off.ensure(8 * ((size_t)n_refs + 1)) ||
+        c->ref_len.ensure(4 * ((size_t)n_refs + 1)) || c->ref_id.ensure(4 * (size_t)n_jobs + 4) ||
+        c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
+        (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
+        c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(4 * (size_t)n_jobs + 4) ||
+        c->tb_next.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
+        return IPX_ERR_NO_DEVICE;
+    if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
+    if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
+
+    hipStream_t s = c->stream;
+    if (read_bytes) HIPCHK(hipMemcpyAsync(c->reads.p, reads, (size_t)read_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->read_off.p, read_off, 8 * ((size_t)n_jobs + 1), hipMemcpyHostToDevice, s));
+    if (ref_bytes) HIPCHK(hipMemcpyAsync(c->refs_raw.p, refs, (size_t)ref_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ref_off.p, ref_off, 8 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->refp_off.p, refp.data(), 8 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ref_len.p, rlen.data(), 4 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
+    if (n_jobs) {
+        HIPCHK(hipMemcpyAsync(c->ref_id.p, ref_id, 4 * (size_t)n_jobs, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->gap_open.p, gap_open, (size_t)n_jobs, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->gap_ext.p, gap_ext, (size_t)n_jobs, hipMemcpyHostToDevice, s));
+        if (mask_len) HIPCHK(hipMemcpyAsync(c->mask_len.p, mask_len, 4 * (size_t)n_jobs, hipMemcpyHostToDevice, s));
+    }
+    // the staged copies above read pageable host memory: finish them before the vectors go away
+    HIPCHK(hipStreamSynchronize(s));
+    // re-pack the windows on the device (4-byte aligned starts, padded, codes sanitised)
+    HipBackend be{c};
+    const bool prof = c->profiling;
+    c->profiling = false;
+    if (n_refs > 0)
+        be.launch(IPX_K_PACK, k_pack_refs, be.flat_grid((int64_t)n_refs * 64), 256, 0, (const int8_t *)c->refs_raw.p,
+                  (const int64_t *)c->ref_off.p, (const int64_t *)c->refp_off.p, (int8_t *)c->refs_packed.p, n_refs);
+    c->profiling = prof;
+    if (be.err != hipSuccess) { set_err("k_pack_refs launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }
+
+    // traceback scratch: tier 0 (band <= 8) for every resident wave, tier 1 (any band) for a few
+    const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
+    int w0 = (int)((n_jobs + 63) / 64);
+    if (w0 < 1) w0 = 1;
+    if (w0 > c->num_cu * 8) w0 = c->num_cu * 8;
+    const size_t lim0 = 512ull << 20;
+    while (w0 > 1 && ipx_tb_bytes_per_wave(s0) * (size_t)w0 > lim0) w0 /= 2;
+    int w1 = 32;
+    const size_t lim1 = 1024ull << 20;
+    while (w1 > 1 && ipx_tb_bytes_per_wave(s1) * (size_t)w1 > lim1) w1 /= 2;
+    c->ws.tb0_waves = w0; c->ws.tb1_waves = w1;
+    if (carve_tb(c, c->tb0, s0, w0, &c->ws.tb0) || carve_tb(c, c->tb1, s1, w1, &c->ws.tb1)) return IPX_ERR_NO_DEVICE;
+
+    // small tables
+    uint32_t *sm = c->small.as<uint32_t>();
+    c->ws.plan.count = sm; sm += 128;
+    c->ws.plan.cursor = sm; sm += 128;
+    c->ws.plan.cls_off = sm; sm += 128;
+    c->ws.plan.tile_off = sm; sm += 128;
+    c->ws.plan.max_cols = nullptr;
+    c->ws.plan.perm = c->perm.as<uint32_t>();
+    c->ws.tb_list = c->tb_list.as<uint32_t>();
+    c->ws.tb_next = c->tb_next.as<uint32_t>();
+    c->ws.tb_list_n = sm; sm += 4;
+    c->ws.tb_next_n = sm; sm += 4;
+    uint32_t *cursor = sm; sm += 4;
+    uint32_t *status = sm; sm += 4;
+
+    IpxBatch &b = c->batch;
+    memset(&b, 0, sizeof b);
+    b.n_jobs = n_jobs; b.n_refs = n_refs;
+    b.reads = c->reads.as<int8_t>(); b.read_off = c->read_off.as<int64_t>();
+    b.refs_packed = c->refs_packed.as<int8_t>(); b.refp_off = c->refp_off.as<int64_t>();
+    b.ref_len = c->ref_len.as<int32_t>(); b.ref_id = c->ref_id.as<int32_t>();
+    b.gap_open = c->gap_open.as<uint8_t>(); b.gap_ext = c->gap_ext.as<uint8_t>();
+    b.mask_len = mask_len ? c->mask_len.as<int32_t>() : nullptr;
+    b.res = c->res.as<IpxResult>();
+    b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
+    b.cigar_cursor = cursor; b.status = status;
+    HIPCHK(hipStreamSynchronize(s));
+    return IPX_OK;
+}
+
+int ipx_run(ipx_ctx *c)
+{
+    if (!c) { set_err("ipx_run: null context"); return IPX_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    IpxBatch &b = c->batch;
+    memcpy(b.mat, c->mat, 25);
+    b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
+    b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
+    b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
+    HipBackend be{c};
+    c->ev_next = 0;
+    c->ev_used.clear();
+    HIPCHK(hipEventRecord(c->run_start, c->stream));
+    be.zero_u32(b.status, 1);
+    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims);
+    HIPCHK(hipEventRecord(c->run_stop, c->stream));
+    if (be.err != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }
+    return IPX_OK;
+}
+
+int ipx_sync(ipx_ctx *c)
+{
+    if (!c) { set_err("ipx_sync: null context"); return IPX_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(&c->last_run_ms, c->run_start, c->run_stop);
+    if (c->profiling) {
+        for (auto &u : c->ev_used) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev_pool[(size_t)u.second], c->ev_pool[(size_t)u.second + 1]) == hipSuccess) {
+                c->k_ms[u.first] += ms;
+                c->k_launches[u.first] += 1;
+            }
+        }
+        c->ev_used.clear();
+    }
+    if (c->n_jobs == 0) return IPX_OK;
+    uint32_t st = 0;
+    HIPCHK(hipMemcpy(&st, c->batch.status, 4, hipMemcpyDeviceToHost));
+    if (st & IPX_STATUS_READ_TOO_LONG) { set_err("a read needs more than %d striped segments", IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
+    if (st & IPX_STATUS_REF_TOO_LONG) { set_err("a window is longer than %d", IPX_MAX_REFLEN); return IPX_ERR_REF_TOO_LONG; }
+    if (st & IPX_STATUS_CIGAR_POOL) { set_err("device cigar pool exhausted (%u ops)", c->cigar_cap); return IPX_ERR_CIGAR_POOL; }
+    if (st & IPX_STATUS_TB_SCRATCH) { set_err("traceback scratch exhausted"); return IPX_ERR_INTERNAL; }
+    return IPX_OK;
+}
+
+int ipx_download(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops)
+{
+    if (!c || (c->n_jobs > 0 && !out)) { set_err("ipx_download: bad argument"); return IPX_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t used = 0;
+    if (c->n_jobs > 0) {
+        HIPCHK(hipMemcpy(out, c->res.p, 32 * (size_t)c->n_jobs, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&used, c->batch.cigar_cursor, 4, hipMemcpyDeviceToHost));
+    }
+    if (n_cigar_ops) *n_cigar_ops = used;
+    if (used) {
+        if (!cigar_pool || (int64_t)used > cigar_cap) { set_err("cigar pool of %lld ops is too small, %u needed", (long long)cigar_cap, used); return IPX_ERR_CIGAR_POOL; }
+        HIPCHK(hipMemcpy(cigar_pool, c->cigar_pool.p, 4 * (size_t)used, hipMemcpyDeviceToHost));
+    }
+    return IPX_OK;
+}
+
+int ipx_align_batch(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const int8_t *refs,
+                    const int64_t *ref_off, const int32_t *ref_id, const uint8_t *gap_open,
+                    const uint8_t *gap_ext, const int32_t *mask_len, int64_t n_jobs, int32_t n_refs,
+                    ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops)
+{
+    int rc = ipx_upload(c, reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len, n_jobs, n_refs);
+    if (rc) return rc;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        if ((rc = ipx_run(c))) return rc;
+        rc = ipx_sync(c);
+        if (rc != IPX_ERR_CIGAR_POOL) break;
+        // device pool too small for this batch: grow and re-run (results are recomputed from scratch)
+        uint64_t want = (uint64_t)c->cigar_cap * 4ull;
+        if (want > 0xFFFFFF00ull) return rc;
+        c->cigar_cap = (uint32_t)want;
+        if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
+    }
+    if (rc) return rc;
+    return ipx_download(c, out, cigar_pool, cigar_cap, n_cigar_ops);
+}
+
+int ipx_set_profiling(ipx_ctx *c, int on)
+{
+    if (!c) return IPX_ERR_ARG;
+    c->profiling = on != 0;
+    memset(c->k_ms, 0, sizeof c->k_ms);
+    memset(c->k_launches, 0, sizeof c->k_launches);
+    return IPX_OK;
+}
+int ipx_num_kernel_classes(void) { return IPX_K_NUM; }
+const char *ipx_kernel_class_name(int k) { return (k >= 0 && k < IPX_K_NUM) ? k_names[k] : ""; }
+int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches)
+{
+    if (!c) return IPX_ERR_ARG;
+    for (int k = 0; k < IPX_K_NUM; ++k) { if (ms) ms[k] = c->k_ms[k]; if (launches) launches[k] = c->k_launches[k]; }
+    return IPX_OK;
+}
+float ipx_last_run_ms(ipx_ctx *c) { return c ? c->last_run_ms : 0.f; }
+
+// ---- synthetic workload generator, host side ----------------------------------------
+static inline uint32_t xs_next(uint64_t &s)
+{
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return (uint32_t)(s >> 11);
+}
+uint64_t ipx_synth_window(uint64_t state, int8_t *ref, int32_t wl)
+{
+    for (int32_t i = 0; i < wl; ++i) ref[i] = (int8_t)(xs_next(state) & 3);
+    return state;
+}
+uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *reads, int64_t n, int32_t rl)
+{
+    for (int64_t k = 0; k < n; ++k) {
+        int8_t *r = reads + k * rl;
+        int32_t st = (int32_t)(xs_next(state) % (uint32_t)(wl - rl + 1)), p = 0, q = st;
+        while (p < rl) {
+            const uint32_t u = xs_next(state) % 1000u;
+            if (q >= wl) { r[p++] = (int8_t)(xs_next(state) & 3); continue; }
+            if (u < 20) { r[p++] = (int8_t)(xs_next(state) & 3); ++q; }         // 2 % substitution
+            else if (u < 25) { ++q; }                                            // 0.5 % deletion
+            else if (u < 30) { r[p++] = (int8_t)(xs_next(state) & 3); }          // 0.5 % insertion
+            else { r[p++] = ref[q++]; }
+        }
+    }
+    return state;
+}
+
+// ---- the reference's four-call interface, executed on GPU 0 ---------------------------------------
+struct _profile {                                  // ssw.c:115-123 (fields this path needs)
+    const int8_t *read;
+    const int8_t *mat;
+    int32_t readLen;
+    int32_t n;
+    int8_t score_size;
+};
+
+static ipx_ctx *g_default_ctx = nullptr;
+static std::mutex g_default_mu;
+
+s_profile *ssw_init(const int8_t *read, const int32_t readLen, const int8_t *mat, const int32_t n, const int8_t score_size)
+{
+    s_profile *p = (s_profile *)calloc(1, sizeof(s_profile));
+    p->read = read; p->mat = mat; p->readLen = readLen; p->n = n; p->score_size = score_size;   // borrowed (ssw.c:803-804)
+    return p;
+}
+void init_destroy(s_profile *p) { free(p); }
+
+s_align *ssw_align(const s_profile *prof, const int8_t *ref, int32_t refLen, const uint8_t weight_gapO,
+                   const uint8_t weight_gapE, const uint8_t flag, const uint16_t filters, const int32_t filterd,
+                   const int32_t maskLen)
+{
+    if (!prof) { fprintf(stderr, "Please call the function ssw_init before ssw_align.\n"); return nullptr; }
+    if (prof->n != 5) { fprintf(stderr, "libindelpost_hip: only the 5-letter DNA matrix of sswpy is supported (n=%d).\n", prof->n); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    if (!g_default_ctx) {
+        g_default_ctx = ipx_create(0);
+        if (!g_default_ctx) { fprintf(stderr, "libindelpost_hip: %s\n", g_err); return nullptr; }
+    }
+    ipx_ctx *c = g_default_ctx;
+    if (ipx_set_params(c, prof->mat, flag, filters, filterd, prof->score_size)) return nullptr;
+    int64_t read_off[2] = {0, prof->readLen}, ref_off[2] = {0, refLen};
+    int32_t rid = 0, mask = maskLen;
+    uint8_t go = weight_gapO, ge = weight_gapE;
+    ipx_result r;
+    std::vector<uint32_t> pool((size_t)prof->readLen + (size_t)refLen + 16);
+    int64_t nops = 0;
+    int rc = ipx_align_batch(c, prof->read, read_off, ref, ref_off, &rid, &go, &ge, &mask, 1, 1, &r, pool.data(),
+                             (int64_t)pool.size(), &nops);
+    if (rc) { fprintf(stderr, "libindelpost_hip: %s\n", g_err); return nullptr; }
+    if (r.mode == IPX_MODE_FAIL) {
+        fprintf(stderr, "Please set 2 to the score_size parameter of the function ssw_init, otherwise the alignment results will be incorrect.\n");
+        return nullptr;                                                                  // ssw.c:848-851
+    }
+    s_align *a = (s_align *)calloc(1, sizeof(s_align));
+    a->score1 = r.score1; a->score2 = r.score2; a->ref_begin1 = r.ref_begin1; a->ref_end1 = r.ref_end1;
+    a->read_begin1 = r.read_begin1; a->read_end1 = r.read_end1; a->ref_end2 = r.ref_end2; a->flag = r.flag;
+    if (r.cigar_len) {
+        a->cigar = (uint32_t *)malloc(sizeof(uint32_t) * r.cigar_len);
+        memcpy(a->cigar, pool.data() + r.cigar_off, sizeof(uint32_t) * r.cigar_len);
+        a->cigarLen = r.cigar_len;
+    }
+    return a;
+}
+void align_destroy(s_align *a) { if (a) { free(a->cigar); free(a); } }
+
+} // extern "C"

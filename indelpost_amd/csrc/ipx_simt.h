@@ -1,0 +1,128 @@
+// ipx_simt.h -- the handful of wavefront primitives the kernels are written against.
+//
+// Product build (hipcc, gfx950): every primitive is a CDNA4 instruction -- DPP lane moves inside a
+// 16-lane row, packed 16-bit VALU (v_pk_*_i16/u16 with clamp), ballots -- no portability layer.
+// Test build (g++ -DIPX_CPU_EMU, tests/emu/): the same kernel source runs under a lock-step
+// 64-fiber wave emulator so the kernel logic can be checked (and sanitised) without a GPU.  The
+// emulator is test infrastructure; the shipped library contains none of it.
+#pragma once
+#include <stdint.h>
+
+typedef uint32_t pk16; // two 16-bit DP cells: lo half = even alignment slot, hi half = odd slot
+
+#if defined(IPX_CPU_EMU)
+// ------------------------------------------------------------------------------------------------
+// lock-step emulation (tests only)
+// ------------------------------------------------------------------------------------------------
+#include <string.h>
+#define IPX_KERNEL
+#define IPX_KERNEL_WAVE
+#define IPX_DEV static inline
+#define IPX_UNROLL
+#define IPX_RESTRICT
+namespace ipx_emu {
+struct LaneCtx { int tid; int bid; int gdim; int bdim; unsigned char *lds; };
+LaneCtx &cur();
+void block_barrier();                              // all fibers of the block rendezvous
+uint32_t exchange(uint32_t v, int src_lane);       // read `v` of lane src_lane (same wave); -1 -> 0
+uint64_t ballot(bool p);
+} // namespace ipx_emu
+#define IPX_TID (ipx_emu::cur().tid)
+#define IPX_BID (ipx_emu::cur().bid)
+#define IPX_GDIM (ipx_emu::cur().gdim)
+#define IPX_BDIM (ipx_emu::cur().bdim)
+#define IPX_LDS_BASE (ipx_emu::cur().lds)
+#define IPX_SYNC() ipx_emu::block_barrier()
+
+IPX_DEV uint32_t xl_shfl(uint32_t v, int src) { return ipx_emu::exchange(v, (IPX_TID & ~63) + src); }
+IPX_DEV uint64_t xl_ballot(bool p) { return ipx_emu::ballot(p); }
+IPX_DEV bool xl_any(bool p) { return ipx_emu::ballot(p) != 0; }
+IPX_DEV uint32_t xl_first(uint32_t v) { return ipx_emu::exchange(v, (IPX_TID & ~63)); }
+IPX_DEV int lane_id() { return IPX_TID & 63; }
+// lane i <- lane i-1 inside its 16-lane row, first lane of the row <- 0   (DPP row_shr:1)
+IPX_DEV uint32_t xl_row_shr1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) ? (IPX_TID - 1) : -1); }
+IPX_DEV uint32_t xl_xor1(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 1); }   // quad_perm [1,0,3,2]
+IPX_DEV uint32_t xl_xor2(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 2); }   // quad_perm [2,3,0,1]
+IPX_DEV uint32_t xl_half_mirror(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 7); }  // row_half_mirror
+IPX_DEV uint32_t xl_mirror(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 15); }      // row_mirror
+
+IPX_DEV int16_t sat16(int v) { return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
+IPX_DEV pk16 pk_make(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); }
+IPX_DEV int pk_lo(pk16 a) { return (int16_t)(a & 0xFFFF); }
+IPX_DEV int pk_hi(pk16 a) { return (int16_t)(a >> 16); }
+IPX_DEV unsigned pk_ulo(pk16 a) { return a & 0xFFFF; }
+IPX_DEV unsigned pk_uhi(pk16 a) { return a >> 16; }
+IPX_DEV pk16 pk_add_sat(pk16 a, pk16 b) { return pk_make(sat16(pk_lo(a) + pk_lo(b)), sat16(pk_hi(a) + pk_hi(b))); }
+IPX_DEV pk16 pk_add(pk16 a, pk16 b) { return pk_make(pk_lo(a) + pk_lo(b), pk_hi(a) + pk_hi(b)); }
+IPX_DEV pk16 pk_sub(pk16 a, pk16 b) { return pk_make(pk_lo(a) - pk_lo(b), pk_hi(a) - pk_hi(b)); }
+IPX_DEV pk16 pk_subus(pk16 a, pk16 b) {
+    unsigned l = pk_ulo(a) > pk_ulo(b) ? pk_ulo(a) - pk_ulo(b) : 0, h = pk_uhi(a) > pk_uhi(b) ? pk_uhi(a) - pk_uhi(b) : 0;
+    return l | (h << 16);
+}
+IPX_DEV pk16 pk_max(pk16 a, pk16 b) { return pk_make(pk_lo(a) > pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) > pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
+IPX_DEV pk16 pk_minu(pk16 a, pk16 b) {
+    unsigned l = pk_ulo(a) < pk_ulo(b) ? pk_ulo(a) : pk_ulo(b), h = pk_uhi(a) < pk_uhi(b) ? pk_uhi(a) : pk_uhi(b);
+    return l | (h << 16);
+}
+IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return (v >> off) & ((1u << width) - 1u); }
+IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+
+#else
+// ------------------------------------------------------------------------------------------------
+// gfx950
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define IPX_KERNEL __global__
+#define IPX_KERNEL_WAVE __global__ __launch_bounds__(64)   // block = one wavefront: the whole VGPR file is available
+#define IPX_DEV __device__ __forceinline__
+#define IPX_UNROLL _Pragma("unroll")
+#define IPX_RESTRICT __restrict__
+#define IPX_TID ((int)threadIdx.x)
+#define IPX_BID ((int)blockIdx.x)
+#define IPX_GDIM ((int)gridDim.x)
+#define IPX_BDIM ((int)blockDim.x)
+extern __shared__ __attribute__((aligned(16))) unsigned char ipx_dyn_lds[];
+#define IPX_LDS_BASE (ipx_dyn_lds)
+#define IPX_SYNC() __syncthreads()
+
+typedef short ipx_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short ipx_u2 __attribute__((ext_vector_type(2)));
+
+IPX_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+IPX_DEV uint32_t xl_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+IPX_DEV uint64_t xl_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+IPX_DEV bool xl_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+IPX_DEV uint32_t xl_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// DPP controls: row_shr:1 = 0x111, quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E,
+// row_mirror = 0x140, row_half_mirror = 0x141.  bound_ctrl=1 -> out-of-row source reads 0.
+IPX_DEV uint32_t xl_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+IPX_DEV uint32_t xl_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
+IPX_DEV uint32_t xl_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
+IPX_DEV uint32_t xl_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); }
+IPX_DEV uint32_t xl_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); }
+
+IPX_DEV pk16 pk_make(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); }
+IPX_DEV int pk_lo(pk16 a) { return (int16_t)(a & 0xFFFF); }
+IPX_DEV int pk_hi(pk16 a) { return (int16_t)(a >> 16); }
+IPX_DEV unsigned pk_ulo(pk16 a) { return a & 0xFFFF; }
+IPX_DEV unsigned pk_uhi(pk16 a) { return a >> 16; }
+#define IPX_S2(x) __builtin_bit_cast(ipx_s2, (x))
+#define IPX_U2(x) __builtin_bit_cast(ipx_u2, (x))
+#define IPX_PK(x) __builtin_bit_cast(uint32_t, (x))
+IPX_DEV pk16 pk_add_sat(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_add_sat(IPX_S2(a), IPX_S2(b))); }  // v_pk_add_i16 clamp
+IPX_DEV pk16 pk_add(pk16 a, pk16 b) { return IPX_PK(IPX_S2(a) + IPX_S2(b)); }                                      // v_pk_add_u16
+IPX_DEV pk16 pk_sub(pk16 a, pk16 b) { return IPX_PK(IPX_S2(a) - IPX_S2(b)); }                                      // v_pk_sub_i16
+IPX_DEV pk16 pk_subus(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_sub_sat(IPX_U2(a), IPX_U2(b))); }      // v_pk_sub_u16 clamp
+IPX_DEV pk16 pk_max(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_max(IPX_S2(a), IPX_S2(b))); }            // v_pk_max_i16
+IPX_DEV pk16 pk_minu(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_min(IPX_U2(a), IPX_U2(b))); }           // v_pk_min_u16
+IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
+IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+#endif
+
+// ---- helpers shared by both builds -------------------------------------------------------------
+// per-half "non-zero -> 0xFFFF" mask
+IPX_DEV pk16 pk_nzmask(pk16 x) { return pk_sub(0u, pk_minu(x, 0x00010001u)); }
+IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
+IPX_DEV pk16 pk_splat(int v) { return pk_make(v, v); }

@@ -1,0 +1,85 @@
+// ipx_types.h -- device-side data model of one alignment batch (shared by the HIP runtime, the
+// kernels and the test-only emulator).  Vocabulary follows the reference: read, reference window,
+// gap open/extension, mask length, score1/score2, CIGAR (ssw.h:55-66, 126-134).
+#pragma once
+#include <stdint.h>
+
+// One result record per job: the fields of s_align (ssw.h:55-66) with the malloc'd cigar pointer
+// replaced by (offset,length) into a caller-owned uint32 pool.  32 bytes.
+struct IpxResult {
+    uint16_t score1;
+    uint16_t score2;
+    int32_t ref_begin1;
+    int32_t ref_end1;
+    int32_t read_begin1;
+    int32_t read_end1;
+    int32_t ref_end2;
+    uint32_t cigar_off;  // first op in the cigar pool (valid when cigar_len > 0)
+    uint16_t cigar_len;  // 0 = no cigar (reference: cigar == NULL)
+    uint8_t flag;        // 0 ok, 1 traceback failed, 2 reverse score < score1 (ssw.c:888-891, 911)
+    uint8_t mode;        // internal: see IPX_MODE_*
+};
+
+enum {
+    IPX_MODE_BYTE = 0,       // score1 came from the 8-bit pass
+    IPX_MODE_WORD = 1,       // 8-bit pass overflowed (score 255), 16-bit pass used (ssw.c:844-847)
+    IPX_MODE_FAIL = 2,       // reference would return NULL (8-bit only profile overflowed, ssw.c:848-851)
+    IPX_MODE_NEED_WORD = 3,  // 8-bit pass overflowed, 16-bit pass still to run
+    IPX_MODE_PENDING = 255,  // not processed yet
+};
+
+enum {
+    IPX_PASS_BYTE_FWD = 0,
+    IPX_PASS_WORD_FWD = 1,
+    IPX_PASS_BYTE_REV = 2,
+    IPX_PASS_WORD_REV = 3,
+    IPX_NUM_PASSES = 4,
+};
+
+#define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels
+#define IPX_NUM_CLASSES (IPX_MAX_SEG + 1)
+#define IPX_MAX_REFLEN 4096  // column maxima are staged in LDS
+#define IPX_REF_PAD 8        // window starts are 4-byte aligned, with >= 4 readable bytes after the end
+
+// The batch as the kernels see it (all pointers are device pointers).
+struct IpxBatch {
+    int64_t n_jobs;
+    int32_t n_refs;
+    const int8_t *reads;        // concatenated read codes 0..4
+    const int64_t *read_off;    // n_jobs+1
+    const int8_t *refs_packed;  // windows re-packed: start 4-byte aligned, padded (k_pack_refs)
+    const int64_t *refp_off;    // n_refs: byte offset of each packed window
+    const int32_t *ref_len;     // n_refs
+    const int32_t *ref_id;      // n_jobs
+    const uint8_t *gap_open;    // n_jobs  (already narrowed to uint8, ssw.h:129-130)
+    const uint8_t *gap_ext;     // n_jobs
+    const int32_t *mask_len;    // n_jobs or nullptr -> max(15, readLen/2)  (sswpy.pyx:209-211)
+    int8_t mat[25];             // 5x5 substitution matrix (sswpy.pyx:306-336)
+    int32_t bias;               // |min(mat)| (ssw.c:795-799)
+    uint8_t flag;               // ssw_align flag (ssw.c:821)
+    uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)
+    uint16_t filters;
+    int32_t filterd;
+    IpxResult *res;             // n_jobs
+    uint32_t *cigar_pool;
+    uint32_t cigar_cap;         // capacity of cigar_pool in ops
+    uint32_t *cigar_cursor;     // bump allocator (1 word)
+    uint32_t *status;           // bit0: cigar pool exhausted, bit1: read too long, bit2: ref too long, bit3: traceback scratch exhausted
+};
+
+// Planner output for one pass: jobs bucketed by segLen class.
+struct IpxPlan {
+    uint32_t *count;      // [IPX_NUM_CLASSES] jobs per class
+    uint32_t *cursor;     // [IPX_NUM_CLASSES] scatter cursors
+    uint32_t *cls_off;    // [IPX_NUM_CLASSES+1] first slot of class in perm
+    uint32_t *tile_off;   // [IPX_NUM_CLASSES+1] first tile of class
+    uint32_t *perm;       // [n_jobs] job ids grouped by class
+    uint32_t *max_cols;   // [IPX_NUM_CLASSES] longest column count in the class (sizes the LDS stage)
+};
+
+enum {
+    IPX_STATUS_CIGAR_POOL = 1,
+    IPX_STATUS_READ_TOO_LONG = 2,
+    IPX_STATUS_REF_TOO_LONG = 4,
+    IPX_STATUS_TB_SCRATCH = 8,
+};

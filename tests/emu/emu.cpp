@@ -1,0 +1,221 @@
+// emu.cpp -- lock-step wavefront emulator for the CPU-only test suite (TEST INFRASTRUCTURE).
+//
+// Compiles the PRODUCT kernel source (indelpost_amd/csrc/ipx_kernels.h, ipx_pipeline.h) with
+// -DIPX_CPU_EMU and runs every thread of a block as a fiber; cross-lane primitives (DPP moves,
+// ballots) rendezvous through a strict round-robin scheduler, so wave-uniform control flow behaves
+// exactly as on the GPU.  This lets `pytest -m "not gpu"` check the kernel logic and the launch
+// sequence against the oracle without a device.  It is not a fallback: the shipped library
+// (libindelpost_hip.so) contains none of this and refuses to run without a GPU.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "../../indelpost_amd/csrc/ipx_pipeline.h"
+
+// ---- minimal x86-64 context switch ----------------------------------------------------------------
+extern "C" void ipx_ctx_switch(void **save_sp, void *load_sp);
+asm(".text\n"
+    ".globl ipx_ctx_switch\n"
+    ".type ipx_ctx_switch,@function\n"
+    "ipx_ctx_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n");
+
+namespace ipx_emu {
+
+struct Fiber {
+    void *sp;
+    char *stack;
+    bool done;
+    LaneCtx lc;
+};
+
+static std::vector<Fiber> g_fibers;
+static int g_cur = -1;
+static void *g_sched_sp;
+static std::function<void()> g_body;
+static std::vector<uint32_t> g_slot[2];
+static std::vector<int> g_parity;          // per fiber: which exchange buffer comes next
+static const size_t STACK_BYTES = 512 * 1024;
+
+LaneCtx &cur() { return g_fibers[g_cur].lc; }
+
+static void yield_to_sched() { ipx_ctx_switch(&g_fibers[g_cur].sp, g_sched_sp); }
+
+static void fiber_entry()
+{
+    g_body();
+    g_fibers[g_cur].done = true;
+    for (;;) yield_to_sched();
+}
+
+void block_barrier() { yield_to_sched(); }
+
+uint32_t exchange(uint32_t v, int src_tid)
+{
+    const int me = g_cur;
+    const int par = g_parity[me];
+    g_parity[me] ^= 1;
+    g_slot[par][me] = v;
+    yield_to_sched();
+    return src_tid >= 0 ? g_slot[par][src_tid] : 0u;
+}
+
+uint64_t ballot(bool p)
+{
+    const int me = g_cur;
+    const int par = g_parity[me];
+    g_parity[me] ^= 1;
+    g_slot[par][me] = p ? 1u : 0u;
+    yield_to_sched();
+    const int base = me & ~63;
+    uint64_t m = 0;
+    const int n = (int)g_fibers.size();
+    for (int k = 0; k < 64 && base + k < n; ++k)
+        if (g_slot[par][base + k]) m |= (1ull << k);
+    return m;
+}
+
+static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::function<void()> &body)
+{
+    std::vector<unsigned char> lds((size_t)lds_bytes + 64, 0xCD);
+    g_fibers.assign((size_t)bdim, Fiber());
+    g_slot[0].assign((size_t)bdim, 0);
+    g_slot[1].assign((size_t)bdim, 0);
+    g_parity.assign((size_t)bdim, 0);
+    g_body = body;
+    for (int t = 0; t < bdim; ++t) {
+        Fiber &f = g_fibers[t];
+        f.stack = (char *)aligned_alloc(64, STACK_BYTES);
+        f.done = false;
+        f.lc.tid = t; f.lc.bid = bid; f.lc.gdim = gdim; f.lc.bdim = bdim; f.lc.lds = lds.data();
+        uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)63;
+        void **sp = (void **)top;
+        *--sp = nullptr;                   // fake return address of fiber_entry's caller
+        *--sp = (void *)&fiber_entry;      // `ret` target of the first switch
+        for (int k = 0; k < 6; ++k) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
+        f.sp = (void *)sp;
+    }
+    for (;;) {
+        bool any = false;
+        for (int t = 0; t < bdim; ++t) {
+            if (g_fibers[t].done) continue;
+            any = true;
+            g_cur = t;
+            ipx_ctx_switch(&g_sched_sp, g_fibers[t].sp);
+        }
+        if (!any) break;
+    }
+    g_cur = -1;
+    for (int t = 0; t < bdim; ++t) free(g_fibers[t].stack);
+    g_fibers.clear();
+}
+
+} // namespace ipx_emu
+
+// ---- launcher with the interface ipx_pipeline.h expects -----------------------------------------
+struct EmuBackend {
+    int launches[IPX_K_NUM];
+    EmuBackend() { memset(launches, 0, sizeof launches); }
+    int dp_grid() const { return 3; }
+    int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
+    void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
+    template <class K, class... A>
+    void launch(int kclass, K kern, int grid, int block, int lds, A... args)
+    {
+        ++launches[kclass];
+        std::function<void()> body = [=]() { kern(args...); };
+        for (int bidx = 0; bidx < grid; ++bidx) ipx_emu::run_block(bidx, grid, block, lds, body);
+    }
+};
+
+template <class T> static T *zalloc(size_t n) { return (T *)calloc(n ? n : 1, sizeof(T)); }
+
+// C entry used by tests/emu_backend.py: same arguments as ipx_align_batch (include/indelpost_hip.h)
+extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, const int8_t *refs,
+                               const int64_t *ref_off, const int32_t *ref_id, const uint8_t *gap_open,
+                               const uint8_t *gap_ext, const int32_t *mask_len, const int8_t *mat,
+                               int64_t n_jobs, int32_t n_refs, int flag, int filters, int filterd,
+                               int score_size, IpxResult *out, uint32_t *cigar_pool, uint32_t cigar_cap,
+                               uint32_t *status_out)
+{
+    EmuBackend be;
+    IpxBatch b;
+    memset(&b, 0, sizeof b);
+    IpxDims d = {0, 0};
+    std::vector<int64_t> refp_off((size_t)n_refs + 1);
+    std::vector<int32_t> ref_len((size_t)n_refs + 1);
+    int64_t tot = 0;
+    for (int r = 0; r < n_refs; ++r) {
+        const int len = (int)(ref_off[r + 1] - ref_off[r]);
+        refp_off[r] = tot;
+        ref_len[r] = len;
+        tot += ((len + 3) & ~3) + IPX_REF_PAD;
+        if (len > d.max_ref_len) d.max_ref_len = len;
+    }
+    for (int64_t i = 0; i < n_jobs; ++i) {
+        const int len = (int)(read_off[i + 1] - read_off[i]);
+        if (len > d.max_read_len) d.max_read_len = len;
+    }
+    int8_t *packed = zalloc<int8_t>((size_t)tot + 64);
+    be.launch(IPX_K_PACK, k_pack_refs, 2, 256, 0, refs, ref_off, (const int64_t *)refp_off.data(), packed, n_refs);
+
+    uint32_t status = 0, cursor = 0;
+    b.n_jobs = n_jobs; b.n_refs = n_refs; b.reads = reads; b.read_off = read_off;
+    b.refs_packed = packed; b.refp_off = refp_off.data(); b.ref_len = ref_len.data(); b.ref_id = ref_id;
+    b.gap_open = gap_open; b.gap_ext = gap_ext; b.mask_len = mask_len;
+    memcpy(b.mat, mat, 25);
+    int bias = 0;
+    for (int k = 0; k < 25; ++k) if (mat[k] < bias) bias = mat[k];
+    b.bias = -bias;
+    b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
+    b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
+
+    IpxWorkspace ws;
+    memset(&ws, 0, sizeof ws);
+    ws.plan.count = zalloc<uint32_t>(IPX_NUM_CLASSES);
+    ws.plan.cursor = zalloc<uint32_t>(IPX_NUM_CLASSES);
+    ws.plan.cls_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
+    ws.plan.tile_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
+    ws.plan.perm = zalloc<uint32_t>((size_t)n_jobs);
+    ws.plan.max_cols = nullptr;
+    ws.tb_list = zalloc<uint32_t>((size_t)n_jobs);
+    ws.tb_next = zalloc<uint32_t>((size_t)n_jobs);
+    ws.tb_list_n = zalloc<uint32_t>(1);
+    ws.tb_next_n = zalloc<uint32_t>(1);
+    const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
+    ws.tb0_waves = 2;
+    ws.tb1_waves = 1;
+    auto mk = [](const IpxTbSizing &s, int waves) {
+        IpxTbScratch t;
+        t.arrcap = s.arrcap; t.dircap = s.dircap; t.cigcap = s.cigcap;
+        t.hb = (int32_t *)malloc(sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
+        t.eb = (int32_t *)malloc(sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
+        t.hc = (int32_t *)malloc(sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
+        t.dir = (uint8_t *)malloc(64 * (size_t)s.dircap * waves);
+        t.cig = (uint32_t *)malloc(sizeof(uint32_t) * 64 * (size_t)s.cigcap * waves);
+        memset(t.hb, 0x5A, sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);   // scratch starts dirty
+        memset(t.eb, 0x5A, sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
+        memset(t.hc, 0x5A, sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
+        memset(t.dir, 0x5A, 64 * (size_t)s.dircap * waves);
+        return t;
+    };
+    ws.tb0 = mk(s0, ws.tb0_waves);
+    ws.tb1 = mk(s1, ws.tb1_waves);
+
+    ipx_run_pipeline(be, b, ws, d);
+
+    *status_out = status;
+    free(packed);
+    free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
+    free(ws.tb_list); free(ws.tb_next); free(ws.tb_list_n); free(ws.tb_next_n);
+    for (IpxTbScratch *t : {&ws.tb0, &ws.tb1}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
+    return 0;
+}

@@ -1,0 +1,69 @@
+"""EmuAligner: the GpuAligner interface on top of tests/emu/libipx_emu.so (TEST INFRASTRUCTURE).
+
+The emulator library is the product kernel source (indelpost_amd/csrc/ipx_kernels.h and the launch
+sequence ipx_pipeline.h) compiled with g++ -DIPX_CPU_EMU and executed by a lock-step 64-fiber wave
+emulator.  It lets the CPU-only suite check kernel logic, the planner and the host code paths
+against the oracle.  It is never imported by the package.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+from indelpost_amd._lib import RESULT_DTYPE
+from indelpost_amd.batch import BatchResult, dna_score_matrix
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libipx_emu.so")
+CSRC = os.path.join(os.path.dirname(HERE), "indelpost_amd", "csrc")
+
+
+def build_emu(force=False):
+    srcs = [os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, h) for h in
+                                                   ("ipx_simt.h", "ipx_types.h", "ipx_kernels.h", "ipx_pipeline.h")]
+    if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_LIB) for s in srcs):
+        return EMU_LIB
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-DIPX_CPU_EMU", "-fPIC", "-shared",
+                           "-U_FORTIFY_SOURCE", "-Wall", "-Wno-unused-function", "-o", EMU_LIB, srcs[0]])
+    return EMU_LIB
+
+
+_EMU_LOCK = threading.Lock()   # the emulator keeps global fiber state: one batch at a time
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class EmuAligner:
+    def __init__(self, device=0, match_score=2, mismatch_penalty=2, matrix=None):
+        self._L = C.CDLL(build_emu())
+        self.device = device
+        self.set_scoring(match_score, mismatch_penalty, matrix)
+
+    def set_scoring(self, match_score=2, mismatch_penalty=2, matrix=None, flag=1, filters=0, filterd=0, score_size=2):
+        self.matrix = dna_score_matrix(match_score, mismatch_penalty) if matrix is None else np.ascontiguousarray(matrix, np.int8)
+        self.flag, self.filters, self.filterd, self.score_size = flag, filters, filterd, score_size
+
+    def align(self, jobs):
+        n = jobs.n_jobs
+        rec = np.zeros(n, RESULT_DTYPE)
+        cap = 2 * int(jobs.read_off[-1]) + 64 * n + 64
+        pool = np.zeros(cap, np.uint32)
+        st = C.c_uint32(0)
+        reads = np.concatenate([jobs.reads, np.zeros(8, np.int8)])
+        refs = np.concatenate([jobs.refs, np.zeros(8, np.int8)])
+        with _EMU_LOCK:
+            self._L.emu_align_batch(_p(reads), _p(jobs.read_off), _p(refs), _p(jobs.ref_off), _p(jobs.ref_id),
+                                    _p(jobs.gap_open), _p(jobs.gap_ext), _p(jobs.mask_len), _p(self.matrix),
+                                    C.c_int64(n), C.c_int32(jobs.n_refs), self.flag, self.filters, self.filterd,
+                                    self.score_size, _p(rec), _p(pool), C.c_uint32(cap), C.byref(st))
+        self.status = st.value
+        used = int((rec["cigar_off"].astype(np.int64) + rec["cigar_len"]).max()) if n else 0
+        return BatchResult(rec, pool[:used])
+
+    def close(self):
+        pass

@@ -1,0 +1,118 @@
+"""Product kernel source + launch sequence under the lock-step wave emulator vs the oracle (CPU).
+
+These tests exercise indelpost_amd/csrc/ipx_kernels.h and ipx_pipeline.h (compiled with
+-DIPX_CPU_EMU) -- the DP passes, planner, traceback and the host-side job-table code -- without a
+GPU.  The GPU parity tests (test_gpu_parity.py) run the same cases through the real C ABI.
+"""
+import numpy as np
+import pytest
+
+from indelpost_amd.batch import JobTable
+from tests.conftest import codes
+
+
+def _compare(res, jobs_py, port, mat):
+    for i, (rd, rf, go, ge) in enumerate(jobs_py):
+        exp = port.align(rd, rf, mat, go, ge)
+        assert res.as_dict(i) == exp, "job %d (read %d bp, window %d bp)" % (i, len(rd), len(rf))
+
+
+def test_emu_golden_subset(emu, oracle_mod, port, golden_c):
+    """Golden vectors from the reference, grouped by scoring so each group is one batch."""
+    groups = {}
+    for k, c in enumerate(golden_c[:160]):
+        groups.setdefault((c["match"], c["mismatch"]), []).append(c)
+    for (ms, mm), cs in groups.items():
+        a = emu(0, ms, mm)
+        jobs = JobTable.from_sequences([codes(c["read"]) for c in cs], [codes(c["ref"]) for c in cs],
+                                       np.arange(len(cs), dtype=np.int32), [c["gap_open"] for c in cs],
+                                       [c["gap_ext"] for c in cs], encoded=True)
+        res = a.align(jobs)
+        assert a.status == 0
+        for i, c in enumerate(cs):
+            assert res.as_dict(i) == c["expect"], "scoring %s case %d" % ((ms, mm), i)
+
+
+def test_emu_config1_like(emu, oracle_mod, port, hip_lib):
+    """BASELINE config 1 shape (150 bp reads, one 300 bp window, defaults), reduced to 48 reads."""
+    from indelpost_amd import synth
+    jobs = synth.config2_jobs(48)
+    a = emu(0, 3, 2)
+    res = a.align(jobs)
+    mat = oracle_mod.dna_matrix(3, 2)
+    ref = jobs.refs
+    _compare(res, [(jobs.reads[i * 150:(i + 1) * 150], ref, 3, 1) for i in range(48)], port, mat)
+    assert (res.records["mode"] == 1).all()        # every 150 bp read overflows the 8-bit pass
+
+
+def test_emu_flags_and_score_size(emu, oracle_mod, port):
+    rng = np.random.default_rng(3)
+    w = rng.integers(0, 4, 120).astype(np.int8)
+    reads = [w[10:70].copy(), w[30:110].copy(), rng.integers(0, 4, 50).astype(np.int8)]
+    reads[0][5] ^= 1
+    mat = oracle_mod.dna_matrix(2, 2)
+    jobs = JobTable.from_sequences(reads, [w], [0, 0, 0], 3, 1, encoded=True)
+    for flag, filters, filterd, ss in [(0, 0, 0, 2), (1, 0, 0, 2), (2, 100, 0, 2), (2, 500, 0, 2), (4, 0, 65, 2),
+                                       (8, 0, 0, 2), (1, 0, 0, 1), (1, 0, 0, 0)]:
+        a = emu(0, 2, 2)
+        a.set_scoring(matrix=mat, flag=flag, filters=filters, filterd=filterd, score_size=ss)
+        res = a.align(jobs)
+        for i, r in enumerate(reads):
+            exp = port.align(r, w, mat, 3, 1, flag=flag, filters=filters, filterd=filterd, score_size=ss)
+            if exp is None:
+                assert res.records[i]["mode"] == 2      # reference returns NULL (ssw.c:848-851)
+            else:
+                assert res.as_dict(i) == exp, (flag, filters, filterd, ss, i)
+
+
+def test_emu_band_escalation_and_long_cigar(emu, oracle_mod, port):
+    """Reads whose traceback band outgrows the tier-0 scratch (large indels) and zero gap penalties."""
+    rng = np.random.default_rng(11)
+    w = rng.integers(0, 4, 400).astype(np.int8)
+    r1 = np.concatenate([w[20:80], w[140:200]])             # 60 bp deletion
+    r2 = np.concatenate([w[50:90], rng.integers(0, 4, 40).astype(np.int8), w[90:130]])   # 40 bp insertion
+    r3 = w[100:220].copy()
+    mat = oracle_mod.dna_matrix(3, 2)
+    reads = [r1, r2, r3, r1, r2]
+    go = [1, 1, 0, 3, 0]
+    ge = [0, 0, 0, 1, 0]
+    jobs = JobTable.from_sequences(reads, [w], [0] * 5, go, ge, encoded=True)
+    a = emu(0, 3, 2)
+    res = a.align(jobs)
+    assert a.status == 0
+    _compare(res, [(reads[i], w, go[i], ge[i]) for i in range(5)], port, mat)
+
+
+def test_emu_degenerate(emu, oracle_mod, port):
+    ref = oracle_mod.encode("ACGTACGTTTGACCAGT")
+    reads = [np.zeros(0, np.int8), np.full(4, 4, np.int8), oracle_mod.encode("A"), oracle_mod.encode("GGGGGGGG"),
+             oracle_mod.encode("ACGTACGTCCCTTGACCAGT")]
+    jobs = JobTable.from_sequences(reads, [ref, np.zeros(0, np.int8)], [0, 0, 0, 0, 1], 3, 1, encoded=True)
+    a = emu(0, 3, 2)
+    res = a.align(jobs)
+    mat = oracle_mod.dna_matrix(3, 2)
+    for i in range(5):
+        exp = port.align(reads[i], ref if i < 4 else np.zeros(0, np.int8), mat, 3, 1)
+        assert res.as_dict(i) == exp, i
+
+
+def test_emu_mixed_lengths_many_windows(emu, oracle_mod, port):
+    """Config-4 shape in miniature: read lengths 75..250, windows 200..600, one tile mixes windows."""
+    rng = np.random.default_rng(5)
+    refs = [rng.integers(0, 4, int(n)).astype(np.int8) for n in (200, 333, 600)]
+    reads, rid = [], []
+    for L in (75, 100, 125, 150, 200, 250) * 3:
+        k = int(rng.integers(0, 3))
+        st = int(rng.integers(0, max(1, len(refs[k]) - L)))
+        r = np.resize(refs[k][st:], L).copy()
+        m = rng.random(L) < 0.03
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        reads.append(r)
+        rid.append(k)
+    jobs = JobTable.from_sequences(reads, refs, rid, 3, 1, encoded=True)
+    a = emu(0, 3, 2)
+    res = a.align(jobs)
+    mat = oracle_mod.dna_matrix(3, 2)
+    _compare(res, [(reads[i], refs[rid[i]], 3, 1) for i in range(len(reads))], port, mat)
+    modes = set(res.records["mode"].tolist())
+    assert modes == {0, 1}      # short reads stay in the 8-bit pass, long ones take the 16-bit pass

@@ -1,0 +1,96 @@
+"""Host-side mirror of the reference interface (SSW / make_aligner / align / align_pileup), job
+tables, sharding and gather -- on CPU, with the emulator standing in for the GPU context."""
+import numpy as np
+import pytest
+
+import indelpost_amd as ip
+from indelpost_amd import sswpy, localn
+from indelpost_amd.batch import JobTable, merge_results, shard_bounds
+
+
+@pytest.fixture()
+def emu_as_gpu(emu, monkeypatch):
+    cache = {}
+
+    def fake(device=0):
+        if device not in cache:
+            cache[device] = emu(device)
+        return cache[device]
+    monkeypatch.setattr(sswpy, "_gpu", fake)
+    monkeypatch.setattr(localn, "_gpu", fake)
+    return fake
+
+
+def test_ssw_class_matches_reference_binding(emu_as_gpu, golden_sswpy):
+    """Alignment tuples captured from the reference's sswpy.SSW (first 40 vectors: all KATs of
+    SURVEY 8c incl. lower case, U->A, start_idx/end_idx, gap_open=len)."""
+    for k, c in enumerate(golden_sswpy[:40]):
+        a = ip.SSW(c["match"], c["mismatch"])
+        a.setReference(c["ref"])
+        a.setRead(c["read"])
+        assert list(a.align(**c["kwargs"])) == c["expect"], "case %d" % k
+
+
+def test_ssw_bytes_and_errors(emu_as_gpu):
+    a = ip.SSW(3, 2)
+    with pytest.raises(ValueError):
+        a.align()                                   # call setReference first (sswpy.pyx:279-280)
+    a.setReference(b"ACGTACGTTTGACCAGT")
+    a.setRead(b"ACGTAGTTTGACCAGT")
+    assert tuple(a.align(3, 1)) == ("5M1D11M", 45, 3, 0, 16, 0, 15)
+    with pytest.raises(ValueError):
+        a.align(start_idx=-1)
+    with pytest.raises(ValueError):
+        a.align(end_idx=100)
+    assert ip.dna_score_matrix(2, 2).reshape(5, 5).tolist() == [[2, -2, -2, -2, 0], [-2, 2, -2, -2, 0],
+                                                               [-2, -2, 2, -2, 0], [-2, -2, -2, 2, 0], [0] * 5]
+
+
+def test_make_aligner_align_and_batch(emu_as_gpu):
+    ref = "ACGTTGCATGCCGATAGGCTTAACGGATCGATCGGGATTACAGCTAGCTAG"
+    reads = ["GCATGCCGATAGGCTTAACGG", "GATCGATCGGATTACAGC", "TTTTTTTT", "NNNNN", "gcatgccgataggcttaacgg"]
+    al = ip.make_aligner(ref, 3, 2)
+    one_by_one = [ip.align(al, r, 3, 1) for r in reads]
+    assert al.align_batch(reads, 3, 1) == one_by_one
+    assert one_by_one[0] == one_by_one[4]
+    pairs = ip.align_pileup(reads, ref[:20] + ref[26:], ref, 3, 2, 3, 1)
+    ref_al, mut_al = ip.make_aligner(ref, 3, 2), ip.make_aligner(ref[:20] + ref[26:], 3, 2)
+    for r, (ra, ma) in zip(reads, pairs):
+        assert ra == ip.align(ref_al, r, 3, 1)
+        assert ma == ip.align(mut_al, r, len(r), 1)           # localn.pyx:253-255
+
+
+def test_gap_penalties_narrow_to_uint8():
+    j = JobTable.from_sequences(["ACGT"], ["ACGT"], [0], 300, 256 + 7)
+    assert j.gap_open[0] == 300 - 256 and j.gap_ext[0] == 7  # ssw.h:129-130
+
+
+def test_shard_and_merge(emu):
+    rng = np.random.default_rng(1)
+    refs = [rng.integers(0, 4, 120).astype(np.int8) for _ in range(3)]
+    reads = [np.resize(refs[i % 3][i:], 40 + i).copy() for i in range(11)]
+    jobs = JobTable.from_sequences(reads, refs, [i % 3 for i in range(11)], 3, 1, encoded=True)
+    whole = emu(0, 3, 2).align(jobs)
+    for k in (1, 2, 3, 4):
+        b = shard_bounds(jobs.n_jobs, k)
+        assert b[0] == 0 and b[-1] == 11 and all(b[i] <= b[i + 1] for i in range(k))
+        parts = [emu(i, 3, 2).align(jobs.shard(b[i], b[i + 1])) for i in range(k)]
+        merged = merge_results(parts)
+        for i in range(11):
+            assert merged.as_dict(i) == whole.as_dict(i)
+
+
+def test_align_sharded_threads(emu):
+    rng = np.random.default_rng(2)
+    w = rng.integers(0, 4, 200).astype(np.int8)
+    reads = [w[i:i + 60].copy() for i in range(0, 90, 10)]
+    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), 3, 1, encoded=True)
+    whole = emu(0, 3, 2).align(jobs)
+    merged = ip.align_sharded(jobs, [emu(0, 3, 2), emu(1, 3, 2)])
+    assert all(merged.as_dict(i) == whole.as_dict(i) for i in range(len(reads)))
+
+
+def test_out_of_scope_shells_say_so():
+    for name in ("Variant", "VariantAlignment", "Contig"):
+        with pytest.raises(NotImplementedError):
+            getattr(ip, name)()
