@@ -196,14 +196,17 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 // ------------------------------------------------------------------------------------------------
 // k_dp_pass: one striped Smith-Waterman pass over a tile of 128/W reads per wavefront
 //   W    = SSE lanes of the reference pass: 16 (8-bit semantics) or 8 (16-bit semantics)
-//   SMAX = largest segLen this instantiation holds in registers (tile's segLen S <= SMAX)
+//   SMAX = segLen capacity held in registers.  EXACT: the tile's segLen S == SMAX is a compile-time
+//          constant, so the segment loop is straight-line code and the profile reads pipeline;
+//          !EXACT (long reads): S <= SMAX is read per tile and every segment step is branch-guarded
 //   REV  = reverse pass (reversed read prefix vs window prefix walked right to left, ssw.c:875-886)
 // Block = one wavefront (64 threads); grid-stride over the tiles of classes [cls_lo, cls_hi].
 // Dynamic LDS: profile 768*SMAX B | column maxima 4*G*maxcols B (forward only) | matrix 32 B
 // ------------------------------------------------------------------------------------------------
-template <int W, int SMAX, bool REV>
+template <int W, int SMAX, bool REV, bool EXACT>
 IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols)
 {
+    constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
     constexpr int NA = 2 * G;
     constexpr bool BYTE = (W == 16);
@@ -222,7 +225,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         // ---- locate the tile: class (= segLen), first slot in perm, number of reads -------------
         int cls = cls_lo;
         while (tile >= p.tile_off[cls + 1]) ++cls;
-        const int S = (int)xl_first((uint32_t)cls);
+        const int S = EXACT ? SMAX : (int)xl_first((uint32_t)cls);
         const uint32_t first = p.cls_off[cls] + (tile - p.tile_off[cls]) * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;
         const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
@@ -284,7 +287,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         IPX_SYNC();
 
         // ---- DP state -----------------------------------------------------------------------------
-        pk16 H[SMAX], E[SMAX], HM[SMAX];
+        pk16 H[SA], E[SA], HM[SA];
         IPX_UNROLL
         for (int j = 0; j < SMAX; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
         pk16 Hlast = 0, best = 0, done = 0, ovf = 0;

@@ -61,7 +61,7 @@ struct ipx_ctx {
     // resident batch
     int64_t n_jobs = 0;
     int32_t n_refs = 0;
-    IpxDims dims = {0, 0, 0, 0};
+    IpxDims dims;
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
@@ -74,8 +74,8 @@ struct ipx_ctx {
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, int>> ev_used;   // (kernel class, index of start event; stop = +1)
     size_t ev_next = 0;
-    float k_ms[IPX_K_NUM * 8];
-    int k_launches[IPX_K_NUM * 8];
+    float k_ms[IPX_NUM_KEYS];
+    int k_launches[IPX_NUM_KEYS];
     hipEvent_t run_start = nullptr, run_stop = nullptr;
     float last_run_ms = 0.f;
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
@@ -157,6 +157,7 @@ ipx_ctx *ipx_create(int device)
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
     ipx_ctx *c = new ipx_ctx();
     c->device = device;
+    memset(&c->dims, 0, sizeof c->dims);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete c; return nullptr; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
@@ -229,7 +230,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     // host-side geometry: packed (4-byte aligned, padded) window offsets and the batch maxima
     std::vector<int64_t> refp((size_t)n_refs + 1);
     std::vector<int32_t> rlen((size_t)n_refs + 1);
-    IpxDims d = {0, 0, 0, 0};
+    IpxDims d;
+    memset(&d, 0, sizeof d);
     int64_t tot = 0;
     for (int32_t r = 0; r < n_refs; ++r) {
         const int64_t len = ref_off[r + 1] - ref_off[r];
@@ -278,7 +280,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     const bool prof = c->profiling;
     c->profiling = false;
     if (n_refs > 0)
-        be.launch(IPX_K_PACK * 8, k_pack_refs, be.flat_grid((int64_t)n_refs * 64), 256, 0, (const int8_t *)c->refs_raw.p,
+        be.launch(IPX_KEY(IPX_K_PACK, 0), k_pack_refs, be.flat_grid((int64_t)n_refs * 64), 256, 0, (const int8_t *)c->refs_raw.p,
                   (const int64_t *)c->ref_off.p, (const int64_t *)c->refp_off.p, (int8_t *)c->refs_packed.p, n_refs);
     c->profiling = prof;
     if (be.err != hipSuccess) { set_err("k_pack_refs launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }
@@ -417,22 +419,24 @@ int ipx_set_profiling(ipx_ctx *c, int on)
     memset(c->k_launches, 0, sizeof c->k_launches);
     return IPX_OK;
 }
-int ipx_num_kernel_classes(void) { return IPX_K_NUM * 8; }
+int ipx_num_kernel_classes(void) { return IPX_NUM_KEYS; }
 const char *ipx_kernel_class_name(int k)
 {
-    // key = kernel class * 8 + segLen bucket; DP kernels are named after the instantiation's SMAX
+    // key = kernel class * 128 + sub; DP kernels are named after their segLen instantiation
     static thread_local char buf[64];
-    if (k < 0 || k >= IPX_K_NUM * 8) return "";
-    const int kc = k >> 3, bk = k & 7;
-    if (kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV && bk < IPX_NUM_BUCKETS) snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], ipx_bucket_smax[bk]);
-    else if (kc == IPX_K_TRACEBACK) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], bk);
-    else snprintf(buf, sizeof buf, "%s%s", k_names[kc], bk ? "_" : "");
+    if (k < 0 || k >= IPX_NUM_KEYS) return "";
+    const int kc = k / 128, sub = k % 128;
+    if (kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) {
+        if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
+        else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
+    } else if (kc == IPX_K_TRACEBACK) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub);
+    else snprintf(buf, sizeof buf, "%s", k_names[kc]);
     return buf;
 }
 int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches)
 {
     if (!c) return IPX_ERR_ARG;
-    for (int k = 0; k < IPX_K_NUM * 8; ++k) { if (ms) ms[k] = c->k_ms[k]; if (launches) launches[k] = c->k_launches[k]; }
+    for (int k = 0; k < IPX_NUM_KEYS; ++k) { if (ms) ms[k] = c->k_ms[k]; if (launches) launches[k] = c->k_launches[k]; }
     return IPX_OK;
 }
 float ipx_last_run_ms(ipx_ctx *c) { return c ? c->last_run_ms : 0.f; }

@@ -122,7 +122,7 @@ static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::fun
 
 // ---- launcher with the interface ipx_pipeline.h expects -----------------------------------------
 struct EmuBackend {
-    int launches[IPX_K_NUM * 8];
+    int launches[IPX_NUM_KEYS];
     EmuBackend() { memset(launches, 0, sizeof launches); }
     int dp_grid() const { return 3; }
     int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
@@ -149,7 +149,8 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     EmuBackend be;
     IpxBatch b;
     memset(&b, 0, sizeof b);
-    IpxDims d = {0, 0, 0, 0};
+    IpxDims d;
+    memset(&d, 0, sizeof d);
     std::vector<int64_t> refp_off((size_t)n_refs + 1);
     std::vector<int32_t> ref_len((size_t)n_refs + 1);
     int64_t tot = 0;
@@ -164,7 +165,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
         ipx_dims_add_read(d, (int)(read_off[i + 1] - read_off[i]));
     }
     int8_t *packed = zalloc<int8_t>((size_t)tot + 64);
-    be.launch(IPX_K_PACK * 8, k_pack_refs, 2, 256, 0, refs, ref_off, (const int64_t *)refp_off.data(), packed, n_refs);
+    be.launch(IPX_KEY(IPX_K_PACK, 0), k_pack_refs, 2, 256, 0, refs, ref_off, (const int64_t *)refp_off.data(), packed, n_refs);
 
     uint32_t status = 0, cursor = 0;
     b.n_jobs = n_jobs; b.n_refs = n_refs; b.reads = reads; b.read_off = read_off;
