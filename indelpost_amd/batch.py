@@ -238,7 +238,13 @@ class GpuAligner:
         ms = np.zeros(k, np.float32)
         cnt = np.zeros(k, np.int32)
         self._check(self._L.ipx_kernel_times(self._ctx, _p(ms), _p(cnt)), "ipx_kernel_times")
-        return {self._L.ipx_kernel_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
+        out = {}
+        for i in range(k):
+            if cnt[i]:
+                name = self._L.ipx_kernel_class_name(i).decode()
+                t, c = out.get(name, (0.0, 0))
+                out[name] = (t + float(ms[i]), c + int(cnt[i]))
+        return out
 
     def last_run_ms(self):
         return float(self._L.ipx_last_run_ms(self._ctx))

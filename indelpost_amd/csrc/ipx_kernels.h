@@ -132,6 +132,10 @@ IPX_DEV int plan_class(const IpxBatch &b, int pass, int64_t i)
         if (b.score_size == 1 || r.mode != IPX_MODE_PENDING) return -1;
         L = readLen; lanes = 16; ncol = refLen;
         break;
+    case IPX_PASS_BYTE_FWD_EXACT:
+        if (r.mode != IPX_MODE_NEED_BYTE_EXACT) return -1;
+        L = readLen; lanes = 16; ncol = refLen;
+        break;
     case IPX_PASS_WORD_FWD:
         if (!((b.score_size == 1 && r.mode == IPX_MODE_PENDING) || r.mode == IPX_MODE_NEED_WORD)) return -1;
         L = readLen; lanes = 8; ncol = refLen;
@@ -158,11 +162,34 @@ IPX_KERNEL void k_plan_zero(IpxPlan p)
     if (t < IPX_NUM_CLASSES) { p.count[t] = 0; p.cursor[t] = 0; }
 }
 
+// Jobs of a wave that fall into the same class share ONE atomic: the wave's first lane of the class
+// adds the population count, every lane derives its slot from its rank in the ballot.
+IPX_DEV uint32_t wave_class_slot(uint32_t *counter, int cls)
+{
+    const int lane = lane_id();
+    uint32_t slot = 0;
+    uint64_t todo = xl_ballot(cls >= 0);
+    while (todo) {                                         // one round per distinct class in the wave
+        const int leader = __builtin_ffsll((long long)todo) - 1;
+        const int c = (int)xl_shfl((uint32_t)cls, leader);
+        const uint64_t m = xl_ballot(cls == c);
+        uint32_t base = 0;
+        if (lane == leader) base = atomic_add_u32(&counter[c], (uint32_t)__builtin_popcountll(m));
+        base = xl_shfl(base, leader);
+        if (cls == c) slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    return slot;
+}
+
 IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
 {
-    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
-        const int cls = plan_class(b, pass, i);
-        if (cls >= 0) atomic_add_u32(&p.count[cls], 1u);
+    const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
+    const int64_t rounds = (b.n_jobs + stride - 1) / stride;
+    for (int64_t q = 0; q < rounds; ++q) {                 // every lane runs every round (wave-wide ballots)
+        const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
+        const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
+        (void)wave_class_slot(p.count, cls);
     }
 }
 
@@ -184,12 +211,13 @@ IPX_KERNEL void k_plan_scan(IpxPlan p, int na)
 
 IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 {
-    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
-        const int cls = plan_class(b, pass, i);
-        if (cls >= 0) {
-            const uint32_t pos = atomic_add_u32(&p.cursor[cls], 1u);
-            p.perm[p.cls_off[cls] + pos] = (uint32_t)i;
-        }
+    const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
+    const int64_t rounds = (b.n_jobs + stride - 1) / stride;
+    for (int64_t q = 0; q < rounds; ++q) {
+        const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
+        const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
+        const uint32_t pos = wave_class_slot(p.cursor, cls);
+        if (cls >= 0) p.perm[p.cls_off[cls] + pos] = (uint32_t)i;
     }
 }
 
@@ -203,7 +231,11 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 // Block = one wavefront (64 threads); grid-stride over the tiles of classes [cls_lo, cls_hi].
 // Dynamic LDS: profile 768*SMAX B | column maxima 4*G*maxcols B (forward only) | matrix 32 B
 // ------------------------------------------------------------------------------------------------
-template <int W, int SMAX, bool REV, bool EXACT>
+//   LOW  = first stage of the 8-bit forward pass: lazy-F carries that could meet the reference's
+//          signed-byte exit test (>= 128+gapE) are dropped instead of stepped.  The result is a lower
+//          bound of the exact pass, so "overflow" is certain; reads that neither overflowed nor lost
+//          a carry are exact; the rest are re-run by the exact instantiation (IPX_MODE_NEED_BYTE_EXACT).
+template <int W, int SMAX, bool REV, bool EXACT, bool LOW>
 IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
@@ -267,6 +299,22 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         const pk16 go = pk_make(gO[0], gO[1]), ge = pk_make(gE[0], gE[1]);
         const pk16 term = pk_make(score1[0], score1[1]);
         const pk16 capm1 = pk_splat(255 - b.bias - 1);          // overflow when colmax >= 255-bias (ssw.c:327)
+        // closed-form lazy-F (below) applies to a read when gap_open > gap_ext
+#ifdef IPX_DEBUG_NOFAST
+        const pk16 fast_static = 0;
+#else
+        const pk16 fast_static = (gO[0] > gE[0] ? 0x0000FFFFu : 0u) | (gO[1] > gE[1] ? 0xFFFF0000u : 0u);
+#endif
+        const pk16 bigthr = pk_make(127 + gE[0], 127 + gE[1]);  // F carry > 127+gapE: signed-byte compare territory
+        pk16 D1, D2, D4, D8;                                    // decay of a carry across 1/2/4/8 whole segments
+        {
+            int d[2][4];
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h)
+                for (int q = 0; q < 4; ++q) { int v = (S * gE[h]) << q; d[h][q] = v > 65535 ? 65535 : v; }
+            D1 = pk_make(d[0][0], d[1][0]); D2 = pk_make(d[0][1], d[1][1]);
+            D4 = pk_make(d[0][2], d[1][2]); D8 = pk_make(d[0][3], d[1][3]);
+        }
 
         // ---- stage the tile's query profile in LDS: int8 [6][S][64][2], row 5 = idle (zeros) -----
         IPX_SYNC();   // previous tile's finalisation reads are done
@@ -290,7 +338,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         pk16 H[SA], E[SA], HM[SA];
         IPX_UNROLL
         for (int j = 0; j < SMAX; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
-        pk16 Hlast = 0, best = 0, done = 0, ovf = 0;
+        pk16 Hlast = 0, best = 0, done = 0, ovf = 0, dropped = 0;
         pk16 endref = BYTE ? 0xFFFFFFFFu : 0u;                      // ssw.c:220 / 427
         const pk16 icol0 = REV ? pk_make(idx0[0], idx0[1]) : 0u;
 
@@ -356,7 +404,43 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 }
             }
 
-            // -- lazy-F (ssw.c:302-313 / 507-518), per-read exit ---------------------------------------
+            // -- lazy-F (ssw.c:302-313 / 507-518) --------------------------------------------------------
+            // The reference passes each lane's final F to the next lane, walks the segments applying
+            // H = max(H, F), F -= gapE, and leaves as soon as no lane has F > H - gapO.  With
+            // gap_open > gap_ext (and, in the 8-bit pass, no carry in signed-compare territory) leaving
+            // early never changes H, so the whole loop equals one max-plus prefix scan over the lanes,
+            //   C_l = max_k sat(Fend[l-1-k] - k*segLen*gapE),   H[l][j] = max(H[l][j], sat(C_l - j*gapE)),
+            // done here with log2(W) DPP row shifts.  Reads outside that regime fall through to the
+            // reference's step-by-step loop below with its per-read, data-dependent exit.
+            {
+                pk16 fe = fast_static;
+                if (BYTE) {
+                    const pk16 big = pk_nzmask(pk_subus(vF, bigthr));
+                    if (LOW) { const pk16 drop = big & fast_static; vF &= ~drop; dropped |= drop; }
+                    else fe &= ~group_or<W>(big);
+                }
+                pk16 x = xl_row_shr1(vF & fe);
+                if (W == 8 && l == 0) x = 0;
+                if (xl_any(x != 0)) {
+                    pk16 y;
+                    y = xl_row_shr<1>(x); if (W == 8 && l < 1) y = 0; x = pk_max(x, pk_subus(y, D1));
+                    y = xl_row_shr<2>(x); if (W == 8 && l < 2) y = 0; x = pk_max(x, pk_subus(y, D2));
+                    y = xl_row_shr<4>(x); if (W == 8 && l < 4) y = 0; x = pk_max(x, pk_subus(y, D4));
+                    if (W == 16) { y = xl_row_shr<8>(x); x = pk_max(x, pk_subus(y, D8)); }
+                    cmx = pk_max(cmx, x);
+                    pk16 a = x;
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) {
+                        if (j < S) {
+                            H[j] = pk_max(H[j], a);
+                            a = pk_subus(a, ge);
+                            if (j == S - 1) Hlast = H[j];
+                        }
+                    }
+                }
+                vF &= ~fe;
+            }
+            // step-by-step loop for the remaining reads, per-read exit
             for (int k = 0; k < W; ++k) {
                 vF = xl_row_shr1(vF);
                 if (W == 8 && l == 0) vF = 0;
@@ -387,6 +471,9 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             const pk16 nb = pk_max(best, cmA);
             const pk16 m = pk_nzmask(pk_sub(nb, best)) & a2;                         // strictly better and still running
             best = pk_select(m, nb, best);
+            // on overflow the reference has already stored the saturated maximum (255-bias) in `max` when it
+            // leaves, but not the column: the end-of-pass search then compares the OLD column with it
+            if (BYTE) best = pk_select(om, pk_add(capm1, 0x00010001u), best);
             endref = pk_select(m, icol, endref);
             if (xl_any(m != 0)) {
                 IPX_UNROLL
@@ -439,9 +526,12 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 key = group_umax<W>(key);
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
+                    const bool lost = LOW && (group_or<W>(dropped) >> (16 * h) & 0xFFFFu) != 0;
                     if (BYTE && overflow) {
                         if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }                 // -> 16-bit pass (ssw.c:844-847)
                         else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851
+                    } else if (lost) {
+                        r.mode = IPX_MODE_NEED_BYTE_EXACT;                                                     // lower bound only: exact 8-bit pass decides
                     } else {
                         r.mode = BYTE ? IPX_MODE_BYTE : IPX_MODE_WORD;
                         r.score1 = (uint16_t)bh;

@@ -40,7 +40,7 @@ static inline void ipx_dims_add_read(IpxDims &d, int len)
 // kernel classes for per-kernel timing (ipx_runtime.hip records HIP events around each launch)
 enum {
     IPX_K_INIT = 0, IPX_K_PLAN, IPX_K_BYTE_FWD, IPX_K_WORD_FWD, IPX_K_BYTE_REV, IPX_K_WORD_REV,
-    IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_NUM
+    IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_NUM
 };
 
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols)
@@ -53,12 +53,12 @@ static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols)
 #define IPX_NUM_KEYS (IPX_K_NUM * 128)
 #define IPX_SUB_GENERIC 65
 
-template <class BE, int W, bool REV>
+template <class BE, int W, bool REV, bool LOW>
 static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int S, int maxcols, int kclass)
 {
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
-        be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true>, be.dp_grid(), 64,                          \
+        be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW>, be.dp_grid(), 64,                          \
                   ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols);                                \
         break;
     switch (S) {
@@ -74,7 +74,7 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 
 // forward passes launch exactly the segLen classes that occur among the reads (known on the host);
 // reverse passes align a read PREFIX, so every class up to the longest read may occur
-template <class BE, int W, bool REV>
+template <class BE, int W, bool REV, bool LOW>
 static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass)
 {
     int top = -1;
@@ -82,11 +82,11 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uin
     bool generic = false;
     for (int c = 0; c <= top; ++c) {
         if (!REV && !has[c]) continue;
-        if (c <= IPX_MAX_EXACT) ipx_launch_dp_class<BE, W, REV>(be, b, p, c, maxcols, kclass);
+        if (c <= IPX_MAX_EXACT) ipx_launch_dp_class<BE, W, REV, LOW>(be, b, p, c, maxcols, kclass);
         else generic = true;
     }
     if (generic)
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false>, be.dp_grid(), 64,
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.dp_grid(), 64,
                   ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, IPX_MAX_EXACT + 1, IPX_MAX_SEG, maxcols);
 }
 
@@ -110,20 +110,23 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
 
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD, 8);
-        ipx_launch_dp<BE, 16, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD);
+        ipx_launch_dp<BE, 16, false, true>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD);
+        // reads whose lower-bound stage was inconclusive: exact 8-bit pass
+        ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD_EXACT, 8);
+        ipx_launch_dp<BE, 16, false, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD_X);
     }
     if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_FWD, 16);
-        ipx_launch_dp<BE, 8, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FWD);
+        ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FWD);
     }
     if (b.flag != 0) {                                           // begin position (ssw.c:872-886)
         if (b.score_size != 1) {
             ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_REV, 8);
-            ipx_launch_dp<BE, 16, true>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_REV);
+            ipx_launch_dp<BE, 16, true, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_REV);
         }
         if (b.score_size != 0) {
             ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_REV, 16);
-            ipx_launch_dp<BE, 8, true>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV);
+            ipx_launch_dp<BE, 8, true, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n);

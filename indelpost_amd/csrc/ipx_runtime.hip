@@ -135,7 +135,7 @@ struct HipBackend {
 };
 
 static const char *k_names[IPX_K_NUM] = {"init", "plan", "dp_byte_fwd", "dp_word_fwd", "dp_byte_rev",
-                                         "dp_word_rev", "tb_list", "traceback", "pack_refs"};
+                                         "dp_word_rev", "tb_list", "traceback", "pack_refs", "dp_byte_fwd_exact"};
 
 extern "C" {
 
@@ -426,7 +426,7 @@ const char *ipx_kernel_class_name(int k)
     static thread_local char buf[64];
     if (k < 0 || k >= IPX_NUM_KEYS) return "";
     const int kc = k / 128, sub = k % 128;
-    if (kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) {
+    if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
     } else if (kc == IPX_K_TRACEBACK) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub);

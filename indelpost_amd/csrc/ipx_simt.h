@@ -41,6 +41,7 @@ IPX_DEV uint32_t xl_first(uint32_t v) { return ipx_emu::exchange(v, (IPX_TID & ~
 IPX_DEV int lane_id() { return IPX_TID & 63; }
 // lane i <- lane i-1 inside its 16-lane row, first lane of the row <- 0   (DPP row_shr:1)
 IPX_DEV uint32_t xl_row_shr1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) ? (IPX_TID - 1) : -1); }
+template <int N> IPX_DEV uint32_t xl_row_shr(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) >= N ? (IPX_TID - N) : -1); }
 IPX_DEV uint32_t xl_xor1(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 1); }   // quad_perm [1,0,3,2]
 IPX_DEV uint32_t xl_xor2(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 2); }   // quad_perm [2,3,0,1]
 IPX_DEV uint32_t xl_half_mirror(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 7); }  // row_half_mirror
@@ -97,6 +98,7 @@ IPX_DEV uint32_t xl_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfi
 // DPP controls: row_shr:1 = 0x111, quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E,
 // row_mirror = 0x140, row_half_mirror = 0x141.  bound_ctrl=1 -> out-of-row source reads 0.
 IPX_DEV uint32_t xl_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+template <int N> IPX_DEV uint32_t xl_row_shr(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true); }   // row_shr:N
 IPX_DEV uint32_t xl_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 IPX_DEV uint32_t xl_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
 IPX_DEV uint32_t xl_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); }

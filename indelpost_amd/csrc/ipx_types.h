@@ -25,6 +25,7 @@ enum {
     IPX_MODE_WORD = 1,       // 8-bit pass overflowed (score 255), 16-bit pass used (ssw.c:844-847)
     IPX_MODE_FAIL = 2,       // reference would return NULL (8-bit only profile overflowed, ssw.c:848-851)
     IPX_MODE_NEED_WORD = 3,  // 8-bit pass overflowed, 16-bit pass still to run
+    IPX_MODE_NEED_BYTE_EXACT = 4,  // 8-bit lower-bound stage inconclusive, exact 8-bit pass still to run
     IPX_MODE_PENDING = 255,  // not processed yet
 };
 
@@ -33,7 +34,8 @@ enum {
     IPX_PASS_WORD_FWD = 1,
     IPX_PASS_BYTE_REV = 2,
     IPX_PASS_WORD_REV = 3,
-    IPX_NUM_PASSES = 4,
+    IPX_PASS_BYTE_FWD_EXACT = 4,
+    IPX_NUM_PASSES = 5,
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels

@@ -65,6 +65,26 @@ def c_level_cases(rng, n):
     return cases
 
 
+# inputs that once exposed a divergence of the GPU path (kept as permanent regression vectors)
+REGRESSIONS = [
+    # reverse 8-bit pass overflows (reverse score > forward score): the reference keeps the saturated
+    # maximum but the previous column (ssw.c:325-331), so read_begin1 falls back to 0
+    dict(read="CNNAACACACACAANACCAACAAAAACACCCCCAACCAANCCAACACAACAAAAANACCCCCNAACNCCACAACACAACCACCCAACCCACCCANACCCNCCANCCCCNNAACCACAACCACNAAAAACCANACAAAACNNNAAACAACCAACANAACCACAACCNACCCNACCCCACANCAACACA",
+         ref="ACCCAAACCAACCCACAAACCCCACCACACCCCACCAAAACCCAAACACACAAACAAACACAAACACAC",
+         match=5, mismatch=4, gap_open=2, gap_ext=2),
+]
+
+
+def regression_cases():
+    ref = O.Backend("reference")
+    out = []
+    for c in REGRESSIONS:
+        e = ref.align(O.encode(c["read"]), O.encode(c["ref"]), O.dna_matrix(c["match"], c["mismatch"]),
+                      c["gap_open"], c["gap_ext"])
+        out.append(dict(c, expect=e))
+    return out
+
+
 def sswpy_cases(rng):
     from ref_sswpy_pkg.sswpy import SSW
     out = []
@@ -115,7 +135,7 @@ def main():
     with open(os.path.join(OUT, "c_level_cases.json"), "w") as f:
         json.dump(dict(source="oracle/_ref/libssw_ref.so = /root/reference/indelpost/ssw.c compiled unmodified "
                               "(ssw_init(...,5,2) + ssw_align(flag=1, maskLen=max(15,len//2)))",
-                       alphabet=LET, cases=c_level_cases(rng, 480)), f, separators=(",", ":"))
+                       alphabet=LET, cases=regression_cases() + c_level_cases(rng, 480)), f, separators=(",", ":"))
     with open(os.path.join(OUT, "sswpy_cases.json"), "w") as f:
         json.dump(dict(source="reference indelpost/sswpy.pyx cythonized in the build container; "
                               "expect = list(Alignment) from SSW(match,mismatch).setReference/setRead/align(**kwargs)",
