@@ -524,9 +524,9 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                     }
                 }
                 key = group_umax<W>(key);
+                const bool lost = LOW && ((group_or<W>(dropped) >> (16 * h)) & 0xFFFFu) != 0;   // (all lanes take part)
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
-                    const bool lost = LOW && (group_or<W>(dropped) >> (16 * h) & 0xFFFFu) != 0;
                     if (BYTE && overflow) {
                         if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }                 // -> 16-bit pass (ssw.c:844-847)
                         else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851

@@ -107,3 +107,81 @@ int ipx_cpu_baseline(const char *libpath, const char *prefix, const int8_t *read
     free(th); free(ws); dlclose(h);
     return 0;
 }
+
+/* ---- full per-job results from the CPU checker (parity stress tests) -------------------------------
+ * Same threading as above; writes one 32-byte record per job with the layout of ipx_result
+ * (include/indelpost_hip.h) except that cigar_off carries an FNV-1a hash of the BAM-encoded ops. */
+typedef struct {
+    uint16_t score1, score2;
+    int32_t ref_begin1, ref_end1, read_begin1, read_end1, ref_end2;
+    uint32_t cigar_hash;
+    uint16_t cigar_len;
+    uint8_t flag, is_null;
+} rec_t;
+
+typedef struct { work_t w; rec_t *out; } work2_t;
+
+static void *worker2(void *arg)
+{
+    work2_t *x = (work2_t *)arg;
+    work_t *w = &x->w;
+    int64_t k;
+    for (k = w->lo; k < w->hi; ++k) {
+        const int8_t *rd = w->reads + w->read_off[k];
+        int32_t rl = (int32_t)(w->read_off[k + 1] - w->read_off[k]);
+        int32_t rid = w->ref_id[k];
+        const int8_t *rf = w->refs + w->ref_off[rid];
+        int32_t fl = (int32_t)(w->ref_off[rid + 1] - w->ref_off[rid]);
+        int32_t mask = rl / 2 < 15 ? 15 : rl / 2;
+        void *p = w->init(rd, rl, w->mat, 5, 2);
+        sal_t *a = w->align(p, rf, fl, w->gapO[k], w->gapE[k], 1, 0, 0, mask);
+        rec_t *r = &x->out[k];
+        r->is_null = a ? 0 : 1;
+        if (a) {
+            uint32_t h = 2166136261u;
+            int q;
+            r->score1 = a->score1; r->score2 = a->score2; r->ref_begin1 = a->ref_begin1; r->ref_end1 = a->ref_end1;
+            r->read_begin1 = a->read_begin1; r->read_end1 = a->read_end1; r->ref_end2 = a->ref_end2;
+            r->flag = (uint8_t)a->flag;
+            r->cigar_len = (uint16_t)(a->cigar ? a->cigarLen : 0);
+            for (q = 0; a->cigar && q < a->cigarLen; ++q) { h ^= a->cigar[q]; h *= 16777619u; }
+            r->cigar_hash = h;
+            w->adestroy(a);
+        }
+        w->idestroy(p);
+    }
+    return NULL;
+}
+
+int ipx_cpu_batch_results(const char *libpath, const char *prefix, const int8_t *reads,
+                          const int64_t *read_off, const int8_t *refs, const int64_t *ref_off,
+                          const int32_t *ref_id, const uint8_t *gapO, const uint8_t *gapE,
+                          const int8_t *mat, int64_t n_jobs, int nthreads, void *out_records)
+{
+    char name[128];
+    void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    pthread_t *th;
+    work2_t *ws;
+    int t;
+    if (!h) { fprintf(stderr, "cpu_batch: dlopen %s: %s\n", libpath, dlerror()); return -1; }
+    if (nthreads < 1) nthreads = 1;
+    th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
+    ws = (work2_t *)calloc((size_t)nthreads, sizeof *ws);
+    for (t = 0; t < nthreads; ++t) {
+        work_t *w = &ws[t].w;
+        snprintf(name, sizeof name, "%sssw_init", prefix);      w->init = (init_fn)dlsym(h, name);
+        snprintf(name, sizeof name, "%sssw_align", prefix);     w->align = (align_fn)dlsym(h, name);
+        snprintf(name, sizeof name, "%salign_destroy", prefix); w->adestroy = (adestroy_fn)dlsym(h, name);
+        snprintf(name, sizeof name, "%sinit_destroy", prefix);  w->idestroy = (idestroy_fn)dlsym(h, name);
+        if (!w->init || !w->align || !w->adestroy || !w->idestroy) { free(th); free(ws); dlclose(h); return -2; }
+        w->reads = reads; w->read_off = read_off; w->refs = refs; w->ref_off = ref_off;
+        w->ref_id = ref_id; w->gapO = gapO; w->gapE = gapE; w->mat = mat;
+        w->lo = n_jobs * t / nthreads;
+        w->hi = n_jobs * (t + 1) / nthreads;
+        ws[t].out = (rec_t *)out_records;
+    }
+    for (t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker2, &ws[t]);
+    for (t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th); free(ws); dlclose(h);
+    return 0;
+}

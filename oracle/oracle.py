@@ -121,6 +121,37 @@ class Backend:
         return sec.value, chk.value, ops.value
 
 
+CPU_REC = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"), ("ref_end1", "<i4"),
+                    ("read_begin1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4"), ("cigar_hash", "<u4"),
+                    ("cigar_len", "<u2"), ("flag", "u1"), ("is_null", "u1")])
+
+
+def cpu_batch_results(backend, jobs, mat, nthreads):
+    """Per-job results of a whole job table from the CPU checker (cpu_baseline.c), threaded.
+    `jobs` is an indelpost_amd.batch.JobTable; returns a CPU_REC array (cigar as FNV-1a hash)."""
+    h = C.CDLL(PORT_LIB)
+    f = h.ipx_cpu_batch_results
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_char_p] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_void_p]
+    out = np.zeros(jobs.n_jobs, CPU_REC)
+    mat = np.ascontiguousarray(mat, np.int8)
+    reads = np.concatenate([jobs.reads, np.zeros(8, np.int8)])
+    refs = np.concatenate([np.zeros(8, np.int8), jobs.refs, np.zeros(8, np.int8)])
+    rc = f(backend.path.encode(), backend.prefix.encode(), reads.ctypes.data, jobs.read_off.ctypes.data,
+           refs.ctypes.data + 8, jobs.ref_off.ctypes.data, jobs.ref_id.ctypes.data, jobs.gap_open.ctypes.data,
+           jobs.gap_ext.ctypes.data, mat.ctypes.data, jobs.n_jobs, nthreads, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("ipx_cpu_batch_results failed: %d" % rc)
+    return out
+
+
+def fnv1a_ops(ops):
+    h = 2166136261
+    for c in ops:
+        h = ((h ^ int(c)) * 16777619) & 0xFFFFFFFF
+    return h
+
+
 def have_reference():
     return os.path.exists(REF_LIB)
 

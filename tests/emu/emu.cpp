@@ -43,6 +43,7 @@ static void *g_sched_sp;
 static std::function<void()> g_body;
 static std::vector<uint32_t> g_slot[2];
 static std::vector<int> g_parity;          // per fiber: which exchange buffer comes next
+static std::vector<long> g_epoch;          // per fiber: number of cross-lane operations executed so far
 static const size_t STACK_BYTES = 512 * 1024;
 
 LaneCtx &cur() { return g_fibers[g_cur].lc; }
@@ -56,7 +57,28 @@ static void fiber_entry()
     for (;;) yield_to_sched();
 }
 
-void block_barrier() { yield_to_sched(); }
+// A cross-lane operation must be reached by every lane of the wave (on the GPU an inactive lane feeds
+// zeros/stale data into DPP and ballots): abort loudly when the lanes of a wave disagree.
+static void check_convergent(int me, const char *what)
+{
+    const int base = me & ~63;
+    const int n = (int)g_fibers.size();
+    // lanes scheduled before `me` have already resumed and may have reached the NEXT operation
+    for (int k = 0; k < 64 && base + k < n; ++k)
+        if ((g_epoch[base + k] < g_epoch[me] || g_epoch[base + k] > g_epoch[me] + (base + k < me ? 1 : 0))) {
+            fprintf(stderr, "ipx_emu: divergent %s: lane %d is at cross-lane op %ld, lane %d at %ld (block %d)\n",
+                    what, me & 63, g_epoch[me], k, g_epoch[base + k], g_fibers[me].lc.bid);
+            abort();
+        }
+}
+
+void block_barrier()
+{
+    const int me = g_cur;
+    ++g_epoch[me];
+    yield_to_sched();
+    check_convergent(me, "barrier");
+}
 
 uint32_t exchange(uint32_t v, int src_tid)
 {
@@ -64,7 +86,9 @@ uint32_t exchange(uint32_t v, int src_tid)
     const int par = g_parity[me];
     g_parity[me] ^= 1;
     g_slot[par][me] = v;
+    ++g_epoch[me];
     yield_to_sched();
+    check_convergent(me, "lane exchange");
     return src_tid >= 0 ? g_slot[par][src_tid] : 0u;
 }
 
@@ -74,7 +98,9 @@ uint64_t ballot(bool p)
     const int par = g_parity[me];
     g_parity[me] ^= 1;
     g_slot[par][me] = p ? 1u : 0u;
+    ++g_epoch[me];
     yield_to_sched();
+    check_convergent(me, "ballot");
     const int base = me & ~63;
     uint64_t m = 0;
     const int n = (int)g_fibers.size();
@@ -90,6 +116,7 @@ static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::fun
     g_slot[0].assign((size_t)bdim, 0);
     g_slot[1].assign((size_t)bdim, 0);
     g_parity.assign((size_t)bdim, 0);
+    g_epoch.assign((size_t)bdim, 0);
     g_body = body;
     for (int t = 0; t < bdim; ++t) {
         Fiber &f = g_fibers[t];

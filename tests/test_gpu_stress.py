@@ -1,0 +1,86 @@
+"""Large randomized parity run on the GPU box: every field of every job against the CPU checker
+(the reference's own ssw.c from oracle/_ref when it travelled with the tree, else the port), using
+all host cores.  Far more adversarial inputs than the per-case tests can afford."""
+import os
+
+import numpy as np
+import pytest
+
+from indelpost_amd.batch import JobTable
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True):
+    refs = []
+    for k in range(n_refs):
+        alpha = 2 if (alpha_mix and k % 4 == 0) else 4
+        w = rng.integers(0, alpha, int(rng.integers(6, 620))).astype(np.int8)
+        if k % 11 == 0:
+            w[rng.integers(0, len(w), max(1, len(w) // 12))] = 4
+        refs.append(w)
+    reads, rid, go, ge = [], [], [], []
+    gaps = [(3, 1), (3, 0), (5, 1), (5, 0), (4, 1), (4, 0), (1, 1), (1, 0), (0, 0), (0, 1), (1, 2), (2, 2), (6, 3),
+            (10, 1), (2, 1), (255, 1)]
+    for i in range(n_jobs):
+        k = int(rng.integers(0, n_refs))
+        w = refs[k]
+        L = int(rng.integers(1, 257))
+        kind = i % 5
+        if kind == 0:
+            r = rng.integers(0, 4, L).astype(np.int8)
+        else:
+            st = int(rng.integers(0, len(w)))
+            err = (0.0, 0.02, 0.06, 0.2)[i % 4]
+            out, q = [], st
+            while len(out) < L:
+                if q >= len(w):
+                    out.append(int(rng.integers(0, 4))); continue
+                u = rng.random()
+                if u < err: out.append(int(rng.integers(0, 4))); q += 1
+                elif u < err * 1.6: q += int(rng.integers(1, 9))
+                elif u < err * 2.2: out.extend(rng.integers(0, 4, int(rng.integers(1, 9))).tolist())
+                else: out.append(int(w[q])); q += 1
+            r = np.array(out[:L], np.int8)
+        if i % 13 == 0:
+            r[rng.integers(0, L, max(1, L // 10))] = 4
+        g = gaps[int(rng.integers(0, len(gaps)))]
+        reads.append(r); rid.append(k)
+        go.append(L if i % 17 == 0 else g[0]); ge.append(g[1])
+    return JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+
+
+@pytest.mark.parametrize("scoring", [(3, 2), (1, 1), (2, 2), (1, 3), (5, 4), (2, 4)])
+def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, capfd):
+    from oracle.oracle import cpu_batch_results, fnv1a_ops
+    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1])
+    n = int(os.environ.get("IPX_STRESS_JOBS", "30000"))
+    jobs = _make_jobs(rng, n, 97)
+    be = oracle_mod.Backend("reference" if oracle_mod.have_reference() else "port")
+    mat = oracle_mod.dna_matrix(*scoring)
+    cores = len(os.sched_getaffinity(0))
+    exp = cpu_batch_results(be, jobs, mat, cores)
+    capfd.readouterr()
+    gpu.set_scoring(*scoring)
+    res = gpu.align(jobs)
+    rec = res.records
+    assert (exp["is_null"] == 0).all()
+    bad = np.zeros(n, bool)
+    for f in ("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2", "cigar_len"):
+        bad |= rec[f] != exp[f]
+    # flag / cigar: the reference reads never-written direction cells in a few degenerate tracebacks
+    # (uninitialised heap, outcome depends on allocator history); those jobs are compared on the DP
+    # fields only, everything else must match exactly
+    defined = (exp["flag"] != 1) & (rec["flag"] != 1)
+    bad_flag = defined & (rec["flag"] != exp["flag"])
+    hashes = np.array([fnv1a_ops(res.cigar_ops(i)) if rec["cigar_len"][i] else 2166136261 for i in range(n)], np.uint32)
+    bad_cig = defined & (hashes != exp["cigar_hash"])
+    undefined = int((~defined).sum())
+    assert undefined <= n // 200, "too many traceback-failure jobs: %d" % undefined
+    # when only one side reports a traceback failure the DP fields still have to agree
+    dp_fields_bad = np.zeros(n, bool)
+    for f in ("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2"):
+        dp_fields_bad |= rec[f] != exp[f]
+    first = np.flatnonzero(dp_fields_bad | bad_flag | bad_cig | (defined & bad))
+    assert len(first) == 0, "scoring %s: %d jobs differ, first %d: gpu %s cpu %s" % (
+        scoring, len(first), first[0], rec[first[0]], exp[first[0]])
