@@ -578,6 +578,148 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *list, uint32_t *list_n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_tb_fast: banded_sw (ssw.c:588-772) for the common case -- first band |refLen-readLen|+1 <= 3 and
+// no band doubling -- entirely in LDS.  One lane per job.  The band rows h_b/e_b/h_c (<= 9 ints) sit
+// in LDS [slot][lane]; the three direction planes of a row's <= 7 cells are packed into ONE 32-bit
+// word per row (4 bits per cell: 0 = never written, else 1 + 4*Hsrc + 2*Fopen + Eopen), also in LDS
+// [row][lane], so a DP row costs one ds_write instead of a byte store per cell, and nothing of the
+// traceback touches HBM.  Cells keep the reference's linear index width_d*i + (j - shift), so
+// out-of-band reads alias exactly as in the reference.  Jobs that need a wider band, a second band
+// iteration (max < score, ssw.c:669), more rows than `rowcap` or more than 32 CIGAR runs are
+// appended to `next` for the general kernel below.
+// Dynamic LDS: 32 B matrix | 3*10*64 ints band rows | 32*64 CIGAR ops | rowcap*64 direction words
+// ------------------------------------------------------------------------------------------------
+#define IPX_TBF_BW 3
+#define IPX_TBF_W (2 * IPX_TBF_BW + 3)      // 9 band slots (+1 spare)
+#define IPX_TBF_CIG 32
+static inline int ipx_tbf_lds_bytes(int rowcap) { return 64 + 3 * (IPX_TBF_W + 1) * 256 + IPX_TBF_CIG * 256 + rowcap * 256; }
+
+IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
+                               uint32_t *next, uint32_t *next_n)
+{
+    const int lane = lane_id();
+    unsigned char *lds = IPX_LDS_BASE;
+    int8_t *matl = (int8_t *)lds;
+    int32_t *hb = (int32_t *)(lds + 64) + lane;                         // [slot*64]
+    int32_t *eb = hb + (IPX_TBF_W + 1) * 64;
+    int32_t *hc = eb + (IPX_TBF_W + 1) * 64;
+    uint32_t *cig = (uint32_t *)(lds + 64 + 3 * (IPX_TBF_W + 1) * 256) + lane;
+    uint32_t *dirw = cig + IPX_TBF_CIG * 64;                            // [row*64]
+    if (lane < 25) matl[lane] = b.mat[lane];
+    IPX_SYNC();
+    const uint32_t n = *list_n;
+
+    for (int64_t base = (int64_t)IPX_BID * 64; base < (int64_t)n; base += (int64_t)IPX_GDIM * 64) {
+        const int64_t li = base + lane;
+        if (li >= (int64_t)n) continue;
+        const int64_t jb = list[li];
+        IpxResult r = b.res[jb];
+        const int rid = b.ref_id[jb];
+        const int fullRef = b.ref_len[rid];
+        const int8_t *refp = b.refs_packed + b.refp_off[rid];
+        const int8_t *readp = b.reads + b.read_off[jb] + r.read_begin1;
+        const int rb = r.ref_begin1;
+        const int refLen = r.ref_end1 - r.ref_begin1 + 1;             // ssw.c:897-899
+        const int readLen = r.read_end1 - r.read_begin1 + 1;
+        const int gapO = b.gap_open[jb], gapE = b.gap_ext[jb];
+        const int score = r.score1;
+        const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+        const int len = refLen > readLen ? refLen : readLen;
+        const int width = bw * 2 + 3, width_d = bw * 2 + 1;
+        bool esc = bw > IPX_TBF_BW || readLen > rowcap;
+        int mx = 0;
+        if (!esc) {
+            for (int q = 0; q < width + 1; ++q) { hb[q * 64] = 0; eb[q * 64] = 0; hc[q * 64] = 0; }   // fresh arrays (ssw.c:607-609, 627)
+            for (int i = 0; i < readLen; ++i) {
+                const int x = i - bw > 0 ? i - bw : 0;                 // band shift of row i (= first column)
+                const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;        // ... of row i-1
+                int end = refLen - 1;
+                if (i + bw < end) end = i + bw;
+                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;                // ssw.c:632
+                hb[0] = 0; eb[0] = 0; hb[edge * 64] = 0; eb[edge * 64] = 0; hc[0] = 0;     // ssw.c:633
+                int rc = readp[i];
+                if ((unsigned)rc > 4u) rc = 4;
+                int f = 0, hleft = 0, u = 0;
+                uint32_t word = 0;
+                for (int j = x; j <= end; ++j) {
+                    u = j - x + 1;                                                         // set_u (ssw.c:92)
+                    const int e = j - xp + 1;
+                    int t1 = i == 0 ? -gapO : hb[e * 64] - gapO;                           // ssw.c:644-648
+                    int t2 = i == 0 ? -gapE : eb[e * 64] - gapE;
+                    const int ev = t1 > t2 ? t1 : t2;
+                    const int de = t1 > t2 ? 1 : 0;
+                    eb[u * 64] = ev;
+                    t1 = hleft - gapO;                                                     // ssw.c:650-653
+                    t2 = f - gapE;
+                    f = t1 > t2 ? t1 : t2;
+                    const int df = t1 > t2 ? 1 : 0;
+                    const int e1 = ev > 0 ? ev : 0;                                        // ssw.c:655-664
+                    const int f1 = f > 0 ? f : 0;
+                    t1 = e1 > f1 ? e1 : f1;
+                    const int ri = rb + j;
+                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    t2 = hb[(e - 1) * 64] + matl[rcode * 5 + rc];                          // h_b[d], d = e-1
+                    const int hv = t1 > t2 ? t1 : t2;
+                    hc[u * 64] = hv;
+                    hleft = hv;
+                    if (hv > mx) mx = hv;
+                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
+                    word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (4 * (j - x));
+                }
+                dirw[i * 64] = word;
+                for (int j = 1; j <= u; ++j) hb[j * 64] = hc[j * 64];                       // ssw.c:666
+            }
+            if (mx < score && bw * 2 <= len) esc = true;                                  // band would double (ssw.c:668-669)
+        }
+        int lcnt = 0, e = 0, op = 0;
+        bool fail = false;
+        if (!esc) {
+            // ---- trace back (ssw.c:673-751) ----
+            int i = readLen - 1, j = refLen - 1, plane = 2, prev = 0;                     // op: 0 M, 1 I, 2 D
+            while (i >= 0 && j > 0) {
+                const int x = i - bw > 0 ? i - bw : 0;
+                const int cell = width_d * i + (j - x);
+                int code = 0;
+                if (cell >= 0) {
+                    const int row = cell / width_d, slot = cell - row * width_d;
+                    if (row < readLen) {
+                        const int v = (int)((dirw[row * 64] >> (4 * slot)) & 15u);
+                        if (v) {
+                            const int de = 2 + ((v - 1) & 1), df = 4 + (((v - 1) >> 1) & 1), dh = (v - 1) >> 2;
+                            code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
+                        }
+                    }
+                }
+                if (code == 1) { --i; --j; plane = 2; op = 0; }
+                else if (code == 2) { --i; plane = 0; op = 1; }
+                else if (code == 3) { --i; plane = 2; op = 1; }
+                else if (code == 4) { --j; plane = 1; op = 2; }
+                else if (code == 5) { --j; plane = 2; op = 2; }
+                else { fail = true; break; }
+                if (op == prev) ++e;
+                else {
+                    ++lcnt;
+                    if (lcnt + 2 > IPX_TBF_CIG) { esc = true; break; }
+                    cig[(lcnt - 1) * 64] = ((uint32_t)e << 4) | (uint32_t)prev;
+                    prev = op;
+                    e = 1;
+                }
+            }
+        }
+        if (esc) { next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb; continue; }
+        if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; continue; }                // ssw.c:911
+        if (op == 0) { ++lcnt; cig[(lcnt - 1) * 64] = ((uint32_t)(e + 1) << 4); }          // ssw.c:734-751
+        else { lcnt += 2; cig[(lcnt - 2) * 64] = ((uint32_t)e << 4) | (uint32_t)op; cig[(lcnt - 1) * 64] = (1u << 4); }
+        const uint32_t off = atomic_add_u32(b.cigar_cursor, (uint32_t)lcnt);
+        if (off + (uint32_t)lcnt > b.cigar_cap) { atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL); continue; }
+        for (int k = 0; k < lcnt; ++k) b.cigar_pool[off + k] = cig[(lcnt - 1 - k) * 64];   // reverse (ssw.c:754-762)
+        r.cigar_off = off;
+        r.cigar_len = (uint16_t)lcnt;
+        b.res[jb] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_traceback: banded affine DP + traceback -> BAM-encoded CIGAR (banded_sw, ssw.c:588-772)
 // One lane per job.  Per-lane scratch (interleaved [slot][lane] so a wave's accesses coalesce):
 //   hb/eb/hc : int32 band rows          (arrcap slots each)

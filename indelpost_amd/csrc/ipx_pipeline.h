@@ -13,9 +13,10 @@
 struct IpxWorkspace {
     IpxPlan plan;
     uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR
+    uint32_t *tb_esc, *tb_esc_n;        // jobs the LDS-resident traceback hands to the general kernel
     uint32_t *tb_next, *tb_next_n;      // jobs whose band outgrew the tier-0 scratch
     IpxTbScratch tb0, tb1;
-    int tb0_waves, tb1_waves;
+    int tbf_waves, tb0_waves, tb1_waves;
 };
 
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
@@ -107,6 +108,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     be.zero_u32(b.cigar_cursor, 1);
     be.zero_u32(ws.tb_list_n, 1);
     be.zero_u32(ws.tb_next_n, 1);
+    be.zero_u32(ws.tb_esc_n, 1);
 
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD, 8);
@@ -130,8 +132,11 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n);
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 0), k_traceback, ws.tb0_waves, 64, 64, b, (const uint32_t *)ws.tb_list,
-                      (const uint32_t *)ws.tb_list_n, ws.tb0, ws.tb_next, ws.tb_next_n);
+            const int rowcap = d.max_read_len > 0 ? d.max_read_len : 1;
+            be.launch(IPX_KEY(IPX_K_TRACEBACK, 2), k_tb_fast, ws.tbf_waves, 64, ipx_tbf_lds_bytes(rowcap), b,
+                      (const uint32_t *)ws.tb_list, (const uint32_t *)ws.tb_list_n, rowcap, ws.tb_esc, ws.tb_esc_n);
+            be.launch(IPX_KEY(IPX_K_TRACEBACK, 0), k_traceback, ws.tb0_waves, 64, 64, b, (const uint32_t *)ws.tb_esc,
+                      (const uint32_t *)ws.tb_esc_n, ws.tb0, ws.tb_next, ws.tb_next_n);
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_traceback, ws.tb1_waves, 64, 64, b, (const uint32_t *)ws.tb_next,
                       (const uint32_t *)ws.tb_next_n, ws.tb1, (uint32_t *)nullptr, (uint32_t *)nullptr);
         }

@@ -65,7 +65,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_next, tb0, tb1;
+    DevBuf perm, tb_list, tb_next, tb_esc, tb0, tb1;
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -181,7 +181,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_next, &c->tb0, &c->tb1})
+                      &c->tb_list, &c->tb_next, &c->tb_esc, &c->tb0, &c->tb1})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -255,7 +255,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
         c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(4 * (size_t)n_jobs + 4) ||
-        c->tb_next.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
+        c->tb_next.ensure(4 * (size_t)n_jobs + 4) || c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
     if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
@@ -287,9 +287,13 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
 
     // traceback scratch: tier 0 (band <= 8) for every resident wave, tier 1 (any band) for a few
     const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
+    int wf = (int)((n_jobs + 63) / 64);
+    if (wf < 1) wf = 1;
+    if (wf > c->num_cu * 8) wf = c->num_cu * 8;
+    c->ws.tbf_waves = wf;
     int w0 = (int)((n_jobs + 63) / 64);
     if (w0 < 1) w0 = 1;
-    if (w0 > c->num_cu * 8) w0 = c->num_cu * 8;
+    if (w0 > c->num_cu * 2) w0 = c->num_cu * 2;          // only what the LDS-resident kernel hands over
     const size_t lim0 = 512ull << 20;
     while (w0 > 1 && ipx_tb_bytes_per_wave(s0) * (size_t)w0 > lim0) w0 /= 2;
     int w1 = 32;
@@ -308,8 +312,10 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.plan.perm = c->perm.as<uint32_t>();
     c->ws.tb_list = c->tb_list.as<uint32_t>();
     c->ws.tb_next = c->tb_next.as<uint32_t>();
+    c->ws.tb_esc = c->tb_esc.as<uint32_t>();
     c->ws.tb_list_n = sm; sm += 4;
     c->ws.tb_next_n = sm; sm += 4;
+    c->ws.tb_esc_n = sm; sm += 4;
     uint32_t *cursor = sm; sm += 4;
     uint32_t *status = sm; sm += 4;
 
@@ -429,7 +435,7 @@ const char *ipx_kernel_class_name(int k)
     if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
-    } else if (kc == IPX_K_TRACEBACK) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub);
+    } else if (kc == IPX_K_TRACEBACK) snprintf(buf, sizeof buf, sub == 2 ? "%s_lds" : "%s_tier%d", k_names[kc], sub);
     else snprintf(buf, sizeof buf, "%s", k_names[kc]);
     return buf;
 }
