@@ -630,6 +630,18 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
         int mx = 0;
         if (!esc) {
             for (int q = 0; q < width + 1; ++q) { hb[q * 64] = 0; eb[q * 64] = 0; hc[q * 64] = 0; }   // fresh arrays (ssw.c:607-609, 627)
+            // The window letters under the band slide by at most one column per row: keep them in a
+            // 64-bit register (byte s = letter of column x+s) and fetch the one new letter, and the next
+            // read letter, a row ahead -- the cell loop itself issues no global load.
+            auto ref_at = [&](int j) -> uint64_t {
+                const int ri = rb + j;
+                int c = (j >= 0 && j < refLen && ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                return (uint64_t)(uint32_t)(c & 0xFF);
+            };
+            uint64_t win = 0;
+            for (int q = 0; q <= bw && q < 8; ++q) win |= ref_at(q) << (8 * q);           // row 0 covers columns 0..bw
+            int rc_next = readLen > 0 ? readp[0] : 0;
+            uint64_t c_next = ref_at(bw + 1);                                           // column entering at row 1
             for (int i = 0; i < readLen; ++i) {
                 const int x = i - bw > 0 ? i - bw : 0;                 // band shift of row i (= first column)
                 const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;        // ... of row i-1
@@ -637,8 +649,14 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
                 if (i + bw < end) end = i + bw;
                 const int edge = end + 1 < width - 1 ? end + 1 : width - 1;                // ssw.c:632
                 hb[0] = 0; eb[0] = 0; hb[edge * 64] = 0; eb[edge * 64] = 0; hc[0] = 0;     // ssw.c:633
-                int rc = readp[i];
+                int rc = rc_next;
                 if ((unsigned)rc > 4u) rc = 4;
+                if (i > 0) {                                           // slide the window to row i
+                    if (x != xp) win >>= 8;
+                    win |= c_next << (8 * (i + bw - x));               // column i+bw (ignored when beyond refLen)
+                }
+                rc_next = i + 1 < readLen ? readp[i + 1] : 0;
+                c_next = ref_at(i + 1 + bw);
                 int f = 0, hleft = 0, u = 0;
                 uint32_t word = 0;
                 for (int j = x; j <= end; ++j) {
@@ -656,8 +674,7 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
                     const int e1 = ev > 0 ? ev : 0;                                        // ssw.c:655-664
                     const int f1 = f > 0 ? f : 0;
                     t1 = e1 > f1 ? e1 : f1;
-                    const int ri = rb + j;
-                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    const int rcode = (int)((win >> (8 * (j - x))) & 0xFFu);
                     t2 = hb[(e - 1) * 64] + matl[rcode * 5 + rc];                          // h_b[d], d = e-1
                     const int hv = t1 > t2 ? t1 : t2;
                     hc[u * 64] = hv;
