@@ -570,40 +570,46 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
     return true;
 }
 
-IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *list, uint32_t *list_n)
+// Jobs are bucketed by their first band width |refLen-readLen|+1 (ssw.c:899): widths 1..3 go to the
+// register/LDS-resident kernel k_tb_fast<BW> (list k = lists + (BW-1)*n_jobs), wider ones straight
+// to the general kernel (`esc`).
+IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *lists_n, uint32_t *esc, uint32_t *esc_n)
 {
     for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
-        if (cigar_needed(b, b.res[i])) list[atomic_add_u32(list_n, 1u)] = (uint32_t)i;
+        const IpxResult r = b.res[i];
+        if (!cigar_needed(b, r)) continue;
+        const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
+        const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+        if (bw <= 3) lists[(int64_t)(bw - 1) * b.n_jobs + atomic_add_u32(&lists_n[bw - 1], 1u)] = (uint32_t)i;
+        else esc[atomic_add_u32(esc_n, 1u)] = (uint32_t)i;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tb_fast: banded_sw (ssw.c:588-772) for the common case -- first band |refLen-readLen|+1 <= 3 and
-// no band doubling -- entirely in LDS.  One lane per job.  The band rows h_b/e_b/h_c (<= 9 ints) sit
-// in LDS [slot][lane]; the three direction planes of a row's <= 7 cells are packed into ONE 32-bit
-// word per row (4 bits per cell: 0 = never written, else 1 + 4*Hsrc + 2*Fopen + Eopen), also in LDS
-// [row][lane], so a DP row costs one ds_write instead of a byte store per cell, and nothing of the
-// traceback touches HBM.  Cells keep the reference's linear index width_d*i + (j - shift), so
-// out-of-band reads alias exactly as in the reference.  Jobs that need a wider band, a second band
-// iteration (max < score, ssw.c:669), more rows than `rowcap` or more than 32 CIGAR runs are
-// appended to `next` for the general kernel below.
-// Dynamic LDS: 32 B matrix | 3*10*64 ints band rows | 32*64 CIGAR ops | rowcap*64 direction words
+// k_tb_fast<BW>: banded_sw (ssw.c:588-772) for the common case -- first band BW = |refLen-readLen|+1
+// in 1..3 and no band doubling.  One lane per job, all lanes of a launch share BW, so a DP row is
+// straight-line code: the band rows h_b/e_b/h_c (2*BW+3 ints each) live in REGISTERS (slot = compile-
+// time index; the one-column band shift of a row is a per-lane select between neighbouring slots),
+// the window letters under the band slide through a 64-bit register, and the three direction planes
+// of the row's 2*BW+1 cells are packed into ONE 32-bit word (4 bits per cell: 0 = never written, else
+// 1 + 4*Hsrc + 2*Fopen + Eopen) kept in LDS [row][lane].  Nothing of the traceback touches HBM except
+// the job's own letters and the CIGAR.  Cells keep the reference's linear index width_d*i + (j-shift),
+// so out-of-band reads alias exactly as in the reference.  Jobs that need a second band iteration
+// (max < score, ssw.c:669), more rows than `rowcap` or more than 32 CIGAR runs go to `next`.
+// Dynamic LDS: 64 B matrix | 32*64 CIGAR ops | rowcap*64 direction words
 // ------------------------------------------------------------------------------------------------
-#define IPX_TBF_BW 3
-#define IPX_TBF_W (2 * IPX_TBF_BW + 3)      // 9 band slots (+1 spare)
 #define IPX_TBF_CIG 32
-static inline int ipx_tbf_lds_bytes(int rowcap) { return 64 + 3 * (IPX_TBF_W + 1) * 256 + IPX_TBF_CIG * 256 + rowcap * 256; }
+static inline int ipx_tbf_lds_bytes(int rowcap) { return 64 + IPX_TBF_CIG * 256 + rowcap * 256; }
 
+template <int BW>
 IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                                uint32_t *next, uint32_t *next_n)
 {
+    constexpr int WD = 2 * BW + 1, W = 2 * BW + 3;
     const int lane = lane_id();
     unsigned char *lds = IPX_LDS_BASE;
     int8_t *matl = (int8_t *)lds;
-    int32_t *hb = (int32_t *)(lds + 64) + lane;                         // [slot*64]
-    int32_t *eb = hb + (IPX_TBF_W + 1) * 64;
-    int32_t *hc = eb + (IPX_TBF_W + 1) * 64;
-    uint32_t *cig = (uint32_t *)(lds + 64 + 3 * (IPX_TBF_W + 1) * 256) + lane;
+    uint32_t *cig = (uint32_t *)(lds + 64) + lane;                      // [k*64]
     uint32_t *dirw = cig + IPX_TBF_CIG * 64;                            // [row*64]
     if (lane < 25) matl[lane] = b.mat[lane];
     IPX_SYNC();
@@ -625,80 +631,88 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
         const int score = r.score1;
         const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
         const int len = refLen > readLen ? refLen : readLen;
-        const int width = bw * 2 + 3, width_d = bw * 2 + 1;
-        bool esc = bw > IPX_TBF_BW || readLen > rowcap;
+        bool esc = bw != BW || readLen > rowcap;
         int mx = 0;
         if (!esc) {
-            for (int q = 0; q < width + 1; ++q) { hb[q * 64] = 0; eb[q * 64] = 0; hc[q * 64] = 0; }   // fresh arrays (ssw.c:607-609, 627)
-            // The window letters under the band slide by at most one column per row: keep them in a
-            // 64-bit register (byte s = letter of column x+s) and fetch the one new letter, and the next
-            // read letter, a row ahead -- the cell loop itself issues no global load.
+            int hb[W + 1], eb[W + 1], hc[W + 1];                        // fresh arrays (ssw.c:607-609, 627)
+            IPX_UNROLL
+            for (int q = 0; q < W + 1; ++q) { hb[q] = 0; eb[q] = 0; hc[q] = 0; }
             auto ref_at = [&](int j) -> uint64_t {
                 const int ri = rb + j;
                 int c = (j >= 0 && j < refLen && ri >= 0 && ri < fullRef) ? refp[ri] : 0;
                 return (uint64_t)(uint32_t)(c & 0xFF);
             };
-            uint64_t win = 0;
-            for (int q = 0; q <= bw && q < 8; ++q) win |= ref_at(q) << (8 * q);           // row 0 covers columns 0..bw
+            uint64_t win = 0;                                           // byte s = letter of column shift+s
+            IPX_UNROLL
+            for (int q = 0; q <= BW; ++q) win |= ref_at(q) << (8 * q);  // row 0 covers columns 0..BW
             int rc_next = readLen > 0 ? readp[0] : 0;
-            uint64_t c_next = ref_at(bw + 1);                                           // column entering at row 1
+            uint64_t c_next = ref_at(BW + 1);                           // column entering at row 1
             for (int i = 0; i < readLen; ++i) {
-                const int x = i - bw > 0 ? i - bw : 0;                 // band shift of row i (= first column)
-                const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;        // ... of row i-1
+                const int x = i - BW > 0 ? i - BW : 0;                  // band shift of row i (= first column)
+                const bool sh = i > BW;                                 // the band moved one column since row i-1
                 int end = refLen - 1;
-                if (i + bw < end) end = i + bw;
-                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;                // ssw.c:632
-                hb[0] = 0; eb[0] = 0; hb[edge * 64] = 0; eb[edge * 64] = 0; hc[0] = 0;     // ssw.c:633
+                if (i + BW < end) end = i + BW;
+                const int nact = end - x + 1;                           // cells of this row
+                const int edge = end + 1 < W - 1 ? end + 1 : W - 1;     // ssw.c:632
+                hb[0] = 0; eb[0] = 0; hc[0] = 0;                        // ssw.c:633
+                IPX_UNROLL
+                for (int q = 1; q < W; ++q) if (q == edge) { hb[q] = 0; eb[q] = 0; }
                 int rc = rc_next;
                 if ((unsigned)rc > 4u) rc = 4;
-                if (i > 0) {                                           // slide the window to row i
-                    if (x != xp) win >>= 8;
-                    win |= c_next << (8 * (i + bw - x));               // column i+bw (ignored when beyond refLen)
+                if (i > 0) {                                            // slide the window to row i
+                    if (sh) win >>= 8;
+                    win |= c_next << (8 * (i + BW - x));                // column i+BW (0 beyond refLen)
                 }
                 rc_next = i + 1 < readLen ? readp[i + 1] : 0;
-                c_next = ref_at(i + 1 + bw);
-                int f = 0, hleft = 0, u = 0;
+                c_next = ref_at(i + 1 + BW);
+                const int8_t *mrow = matl + rc;                         // mat[ref*5 + read]
+                int f = 0, hleft = 0;
                 uint32_t word = 0;
-                for (int j = x; j <= end; ++j) {
-                    u = j - x + 1;                                                         // set_u (ssw.c:92)
-                    const int e = j - xp + 1;
-                    int t1 = i == 0 ? -gapO : hb[e * 64] - gapO;                           // ssw.c:644-648
-                    int t2 = i == 0 ? -gapE : eb[e * 64] - gapE;
+                IPX_UNROLL
+                for (int s2 = 0; s2 < WD; ++s2) {
+                    const bool act = s2 < nact;
+                    const int u = s2 + 1;                               // set_u (ssw.c:92); e = u + sh, d = e - 1
+                    const int hbe = sh ? hb[u + 1] : hb[u];
+                    const int ebe = sh ? eb[u + 1] : eb[u];
+                    const int hbd = sh ? hb[u] : hb[u - 1];
+                    int t1 = i == 0 ? -gapO : hbe - gapO;               // ssw.c:644-648
+                    int t2 = i == 0 ? -gapE : ebe - gapE;
                     const int ev = t1 > t2 ? t1 : t2;
                     const int de = t1 > t2 ? 1 : 0;
-                    eb[u * 64] = ev;
-                    t1 = hleft - gapO;                                                     // ssw.c:650-653
+                    t1 = hleft - gapO;                                  // ssw.c:650-653
                     t2 = f - gapE;
-                    f = t1 > t2 ? t1 : t2;
+                    const int fv = t1 > t2 ? t1 : t2;
                     const int df = t1 > t2 ? 1 : 0;
-                    const int e1 = ev > 0 ? ev : 0;                                        // ssw.c:655-664
-                    const int f1 = f > 0 ? f : 0;
+                    const int e1 = ev > 0 ? ev : 0;                     // ssw.c:655-664
+                    const int f1 = fv > 0 ? fv : 0;
                     t1 = e1 > f1 ? e1 : f1;
-                    const int rcode = (int)((win >> (8 * (j - x))) & 0xFFu);
-                    t2 = hb[(e - 1) * 64] + matl[rcode * 5 + rc];                          // h_b[d], d = e-1
+                    const int rcode = (int)((win >> (8 * s2)) & 0xFFu);
+                    t2 = hbd + mrow[rcode * 5];
                     const int hv = t1 > t2 ? t1 : t2;
-                    hc[u * 64] = hv;
-                    hleft = hv;
-                    if (hv > mx) mx = hv;
                     const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
-                    word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (4 * (j - x));
+                    if (act) {
+                        eb[u] = ev; f = fv; hc[u] = hv; hleft = hv;
+                        if (hv > mx) mx = hv;
+                        word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (4 * s2);
+                    }
                 }
                 dirw[i * 64] = word;
-                for (int j = 1; j <= u; ++j) hb[j * 64] = hc[j * 64];                       // ssw.c:666
+                IPX_UNROLL
+                for (int q = 1; q <= WD; ++q) if (q <= nact) hb[q] = hc[q];   // ssw.c:666
             }
-            if (mx < score && bw * 2 <= len) esc = true;                                  // band would double (ssw.c:668-669)
+            if (mx < score && BW * 2 <= len) esc = true;                // band would double (ssw.c:668-669)
         }
         int lcnt = 0, e = 0, op = 0;
         bool fail = false;
         if (!esc) {
             // ---- trace back (ssw.c:673-751) ----
-            int i = readLen - 1, j = refLen - 1, plane = 2, prev = 0;                     // op: 0 M, 1 I, 2 D
+            int i = readLen - 1, j = refLen - 1, plane = 2, prev = 0;   // op: 0 M, 1 I, 2 D
             while (i >= 0 && j > 0) {
-                const int x = i - bw > 0 ? i - bw : 0;
-                const int cell = width_d * i + (j - x);
+                const int x = i - BW > 0 ? i - BW : 0;
+                const int cell = WD * i + (j - x);
                 int code = 0;
                 if (cell >= 0) {
-                    const int row = cell / width_d, slot = cell - row * width_d;
+                    const int row = cell / WD, slot = cell - row * WD;
                     if (row < readLen) {
                         const int v = (int)((dirw[row * 64] >> (4 * slot)) & 15u);
                         if (v) {

@@ -254,7 +254,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         c->ref_len.ensure(4 * ((size_t)n_refs + 1)) || c->ref_id.ensure(4 * (size_t)n_jobs + 4) ||
         c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
-        c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(4 * (size_t)n_jobs + 4) ||
+        c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(12 * (size_t)n_jobs + 16) ||
         c->tb_next.ensure(4 * (size_t)n_jobs + 4) || c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
@@ -435,7 +435,7 @@ const char *ipx_kernel_class_name(int k)
     if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
-    } else if (kc == IPX_K_TRACEBACK) snprintf(buf, sizeof buf, sub == 2 ? "%s_lds" : "%s_tier%d", k_names[kc], sub);
+    } else if (kc == IPX_K_TRACEBACK) { if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
     else snprintf(buf, sizeof buf, "%s", k_names[kc]);
     return buf;
 }

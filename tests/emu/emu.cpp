@@ -213,11 +213,11 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.plan.tile_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
     ws.plan.perm = zalloc<uint32_t>((size_t)n_jobs);
     ws.plan.max_cols = nullptr;
-    ws.tb_list = zalloc<uint32_t>((size_t)n_jobs);
+    ws.tb_list = zalloc<uint32_t>(3 * (size_t)n_jobs);
     ws.tb_next = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc_n = zalloc<uint32_t>(1);
-    ws.tb_list_n = zalloc<uint32_t>(1);
+    ws.tb_list_n = zalloc<uint32_t>(4);
     ws.tb_next_n = zalloc<uint32_t>(1);
     const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
     ws.tb0_waves = 2;
