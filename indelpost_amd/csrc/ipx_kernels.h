@@ -570,47 +570,65 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
     return true;
 }
 
-// Jobs are bucketed by their first band width |refLen-readLen|+1 (ssw.c:899): widths 1..3 go to the
-// register/LDS-resident kernel k_tb_fast<BW> (list k = lists + (BW-1)*n_jobs), wider ones straight
-// to the general kernel (`esc`).
-IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *lists_n, uint32_t *esc, uint32_t *esc_n)
+// Jobs are bucketed by their first band width |refLen-readLen|+1 (ssw.c:899): widths 1..7 go to the
+// register/LDS-resident kernel k_tb_fast<BW> (list BW-1 = lists + (BW-1)*n_jobs, counter BW-1), wider
+// ones straight to the general kernel (list 7 = `esc`, counter 7).
+#define IPX_TBF_MAXBW 7
+IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc)
 {
-    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
-        const IpxResult r = b.res[i];
-        if (!cigar_needed(b, r)) continue;
-        const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
-        const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-        if (bw <= 3) lists[(int64_t)(bw - 1) * b.n_jobs + atomic_add_u32(&lists_n[bw - 1], 1u)] = (uint32_t)i;
-        else esc[atomic_add_u32(esc_n, 1u)] = (uint32_t)i;
+    const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
+    const int64_t rounds = (b.n_jobs + stride - 1) / stride;
+    for (int64_t q = 0; q < rounds; ++q) {                 // every lane runs every round (wave-wide ballots)
+        const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
+        int cls = -1;
+        if (i < b.n_jobs) {
+            const IpxResult r = b.res[i];
+            if (cigar_needed(b, r)) {
+                const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
+                const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+                cls = bw <= IPX_TBF_MAXBW ? bw - 1 : IPX_TBF_MAXBW;
+            }
+        }
+        const uint32_t slot = wave_class_slot(counters, cls);
+        if (cls >= 0) {
+            if (cls < IPX_TBF_MAXBW) lists[(int64_t)cls * b.n_jobs + slot] = (uint32_t)i;
+            else esc[slot] = (uint32_t)i;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_tb_fast<BW>: banded_sw (ssw.c:588-772) for the common case -- first band BW = |refLen-readLen|+1
-// in 1..3 and no band doubling.  One lane per job, all lanes of a launch share BW, so a DP row is
+// in 1..7 and no band doubling.  One lane per job, all lanes of a launch share BW, so a DP row is
 // straight-line code: the band rows h_b/e_b/h_c (2*BW+3 ints each) live in REGISTERS (slot = compile-
 // time index; the one-column band shift of a row is a per-lane select between neighbouring slots),
-// the window letters under the band slide through a 64-bit register, and the three direction planes
-// of the row's 2*BW+1 cells are packed into ONE 32-bit word (4 bits per cell: 0 = never written, else
-// 1 + 4*Hsrc + 2*Fopen + Eopen) kept in LDS [row][lane].  Nothing of the traceback touches HBM except
+// the window letters under the band slide through a 128-bit register pair, and the three direction
+// planes of the row's 2*BW+1 cells are packed into ONE word (32 bit for BW <= 3, 64 bit for BW 4..7;
+// 4 bits per cell: 0 = never written, else 1 + 4*Hsrc + 2*Fopen + Eopen) kept in LDS [row][lane].  Nothing of the traceback touches HBM except
 // the job's own letters and the CIGAR.  Cells keep the reference's linear index width_d*i + (j-shift),
 // so out-of-band reads alias exactly as in the reference.  Jobs that need a second band iteration
 // (max < score, ssw.c:669), more rows than `rowcap` or more than 32 CIGAR runs go to `next`.
-// Dynamic LDS: 64 B matrix | 32*64 CIGAR ops | rowcap*64 direction words
+// Dynamic LDS: 64 B matrix | 32*64 CIGAR ops | rowcap*64 direction words (4 or 8 bytes)
 // ------------------------------------------------------------------------------------------------
 #define IPX_TBF_CIG 32
-static inline int ipx_tbf_lds_bytes(int rowcap) { return 64 + IPX_TBF_CIG * 256 + rowcap * 256; }
+static inline int ipx_tbf_lds_bytes(int bw, int rowcap) { return 64 + IPX_TBF_CIG * 256 + rowcap * (bw <= 3 ? 256 : 512); }
+template <int BW> struct IpxTbWord { typedef uint32_t type; };
+template <> struct IpxTbWord<4> { typedef uint64_t type; };
+template <> struct IpxTbWord<5> { typedef uint64_t type; };
+template <> struct IpxTbWord<6> { typedef uint64_t type; };
+template <> struct IpxTbWord<7> { typedef uint64_t type; };
 
 template <int BW>
 IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                                uint32_t *next, uint32_t *next_n)
 {
     constexpr int WD = 2 * BW + 1, W = 2 * BW + 3;
+    typedef typename IpxTbWord<BW>::type word_t;
     const int lane = lane_id();
     unsigned char *lds = IPX_LDS_BASE;
     int8_t *matl = (int8_t *)lds;
     uint32_t *cig = (uint32_t *)(lds + 64) + lane;                      // [k*64]
-    uint32_t *dirw = cig + IPX_TBF_CIG * 64;                            // [row*64]
+    word_t *dirw = (word_t *)(lds + 64 + IPX_TBF_CIG * 256) + lane;     // [row*64]
     if (lane < 25) matl[lane] = b.mat[lane];
     IPX_SYNC();
     const uint32_t n = *list_n;
@@ -642,9 +660,10 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
                 int c = (j >= 0 && j < refLen && ri >= 0 && ri < fullRef) ? refp[ri] : 0;
                 return (uint64_t)(uint32_t)(c & 0xFF);
             };
-            uint64_t win = 0;                                           // byte s = letter of column shift+s
+            // byte s of (win1:win0) = letter of column shift+s
+            uint64_t win0 = 0, win1 = 0;
             IPX_UNROLL
-            for (int q = 0; q <= BW; ++q) win |= ref_at(q) << (8 * q);  // row 0 covers columns 0..BW
+            for (int q = 0; q <= BW; ++q) win0 |= ref_at(q) << (8 * q);  // row 0 covers columns 0..BW (BW <= 7)
             int rc_next = readLen > 0 ? readp[0] : 0;
             uint64_t c_next = ref_at(BW + 1);                           // column entering at row 1
             for (int i = 0; i < readLen; ++i) {
@@ -660,14 +679,16 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
                 int rc = rc_next;
                 if ((unsigned)rc > 4u) rc = 4;
                 if (i > 0) {                                            // slide the window to row i
-                    if (sh) win >>= 8;
-                    win |= c_next << (8 * (i + BW - x));                // column i+BW (0 beyond refLen)
+                    if (sh) { win0 = (win0 >> 8) | (win1 << 56); win1 >>= 8; }
+                    const int pos = i + BW - x;                         // column i+BW (letter 0 beyond refLen)
+                    if (pos < 8) win0 |= c_next << (8 * pos);
+                    else win1 |= c_next << (8 * (pos - 8));
                 }
                 rc_next = i + 1 < readLen ? readp[i + 1] : 0;
                 c_next = ref_at(i + 1 + BW);
                 const int8_t *mrow = matl + rc;                         // mat[ref*5 + read]
                 int f = 0, hleft = 0;
-                uint32_t word = 0;
+                word_t word = 0;
                 IPX_UNROLL
                 for (int s2 = 0; s2 < WD; ++s2) {
                     const bool act = s2 < nact;
@@ -686,14 +707,14 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
                     const int e1 = ev > 0 ? ev : 0;                     // ssw.c:655-664
                     const int f1 = fv > 0 ? fv : 0;
                     t1 = e1 > f1 ? e1 : f1;
-                    const int rcode = (int)((win >> (8 * s2)) & 0xFFu);
+                    const int rcode = (int)(((s2 < 8 ? win0 >> (8 * s2) : win1 >> (8 * (s2 - 8)))) & 0xFFu);
                     t2 = hbd + mrow[rcode * 5];
                     const int hv = t1 > t2 ? t1 : t2;
                     const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
                     if (act) {
                         eb[u] = ev; f = fv; hc[u] = hv; hleft = hv;
                         if (hv > mx) mx = hv;
-                        word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (4 * s2);
+                        word |= (word_t)(1 + dh * 4 + df * 2 + de) << (4 * s2);
                     }
                 }
                 dirw[i * 64] = word;

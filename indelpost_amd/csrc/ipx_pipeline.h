@@ -12,7 +12,7 @@
 
 struct IpxWorkspace {
     IpxPlan plan;
-    uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: 3 lists (first band 1..3) of n_jobs slots, 3 counters
+    uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: 7 lists (first band 1..7) of n_jobs slots; 8 counters, the 8th = tb_esc_n
     uint32_t *tb_esc, *tb_esc_n;        // jobs the LDS-resident traceback hands to the general kernel
     uint32_t *tb_next, *tb_next_n;      // jobs whose band outgrew the tier-0 scratch
     IpxTbScratch tb0, tb1;
@@ -106,9 +106,8 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     const int maxcols = d.max_ref_len + 4;
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(b.cigar_cursor, 1);
-    be.zero_u32(ws.tb_list_n, 3);
+    be.zero_u32(ws.tb_list_n, 8);
     be.zero_u32(ws.tb_next_n, 1);
-    be.zero_u32(ws.tb_esc_n, 1);
 
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD, 8);
@@ -131,15 +130,15 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             ipx_launch_dp<BE, 8, true, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
-            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n,
-                      ws.tb_esc, ws.tb_esc_n);
+            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
             const int rowcap = d.max_read_len > 0 ? d.max_read_len : 1;
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 2), k_tb_fast<1>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(rowcap), b,
-                      (const uint32_t *)ws.tb_list, (const uint32_t *)ws.tb_list_n, rowcap, ws.tb_esc, ws.tb_esc_n);
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 3), k_tb_fast<2>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(rowcap), b,
-                      (const uint32_t *)(ws.tb_list + b.n_jobs), (const uint32_t *)(ws.tb_list_n + 1), rowcap, ws.tb_esc, ws.tb_esc_n);
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 4), k_tb_fast<3>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(rowcap), b,
-                      (const uint32_t *)(ws.tb_list + 2 * b.n_jobs), (const uint32_t *)(ws.tb_list_n + 2), rowcap, ws.tb_esc, ws.tb_esc_n);
+#define IPX_TBF_LAUNCH(BW)                                                                                        \
+    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(BW, rowcap), b, \
+              (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
+              rowcap, ws.tb_esc, ws.tb_esc_n);
+            IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)
+            IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
+#undef IPX_TBF_LAUNCH
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 0), k_traceback, ws.tb0_waves, 64, 64, b, (const uint32_t *)ws.tb_esc,
                       (const uint32_t *)ws.tb_esc_n, ws.tb0, ws.tb_next, ws.tb_next_n);
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_traceback, ws.tb1_waves, 64, 64, b, (const uint32_t *)ws.tb_next,

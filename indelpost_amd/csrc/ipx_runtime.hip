@@ -254,7 +254,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         c->ref_len.ensure(4 * ((size_t)n_refs + 1)) || c->ref_id.ensure(4 * (size_t)n_jobs + 4) ||
         c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
-        c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(12 * (size_t)n_jobs + 16) ||
+        c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
         c->tb_next.ensure(4 * (size_t)n_jobs + 4) || c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
@@ -313,9 +313,9 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb_list = c->tb_list.as<uint32_t>();
     c->ws.tb_next = c->tb_next.as<uint32_t>();
     c->ws.tb_esc = c->tb_esc.as<uint32_t>();
-    c->ws.tb_list_n = sm; sm += 4;
+    c->ws.tb_list_n = sm; sm += 8;
+    c->ws.tb_esc_n = c->ws.tb_list_n + 7;
     c->ws.tb_next_n = sm; sm += 4;
-    c->ws.tb_esc_n = sm; sm += 4;
     uint32_t *cursor = sm; sm += 4;
     uint32_t *status = sm; sm += 4;
 

@@ -213,12 +213,13 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.plan.tile_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
     ws.plan.perm = zalloc<uint32_t>((size_t)n_jobs);
     ws.plan.max_cols = nullptr;
-    ws.tb_list = zalloc<uint32_t>(3 * (size_t)n_jobs);
+    ws.tb_list = zalloc<uint32_t>(7 * (size_t)n_jobs);
     ws.tb_next = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc = zalloc<uint32_t>((size_t)n_jobs);
-    ws.tb_esc_n = zalloc<uint32_t>(1);
-    ws.tb_list_n = zalloc<uint32_t>(4);
+    ws.tb_esc_n = nullptr;
+    ws.tb_list_n = zalloc<uint32_t>(8);
     ws.tb_next_n = zalloc<uint32_t>(1);
+    ws.tb_esc_n = ws.tb_list_n + 7;
     const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
     ws.tb0_waves = 2;
     ws.tbf_waves = 2;
@@ -245,7 +246,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     *status_out = status;
     free(packed);
     free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
-    free(ws.tb_list); free(ws.tb_next); free(ws.tb_esc); free(ws.tb_esc_n); free(ws.tb_list_n); free(ws.tb_next_n);
+    free(ws.tb_list); free(ws.tb_next); free(ws.tb_esc); free(ws.tb_list_n); free(ws.tb_next_n);
     for (IpxTbScratch *t : {&ws.tb0, &ws.tb1}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
     return 0;
 }
