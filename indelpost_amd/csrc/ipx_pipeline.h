@@ -8,6 +8,7 @@
 // No host synchronisation happens between the stages: which job takes which branch is decided by
 // the planner kernels on the device.
 #pragma once
+#include <stdlib.h>
 #include "ipx_kernels.h"
 
 struct IpxWorkspace {
@@ -46,7 +47,8 @@ enum {
 
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols)
 {
-    return 768 * SMAX + (rev ? 0 : 4 * (64 / W) * maxcols) + 64;
+    static const int extra = getenv("IPX_DEBUG_EXTRA_LDS") ? atoi(getenv("IPX_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
+    return 640 * ipx_prof_row_bytes(SMAX) + (rev ? 0 : 4 * (64 / W) * maxcols) + 64 + extra;
 }
 
 // timing key of a launch: kernel class * 128 + sub (DP kernels: sub = segLen, 65 = long-read kernel)
@@ -103,7 +105,8 @@ static void ipx_plan_pass(BE &be, const IpxBatch &b, const IpxPlan &p, int pass,
 template <class BE>
 static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d)
 {
-    const int maxcols = d.max_ref_len + 4;
+    int maxcols = d.max_ref_len + 4;
+    if (getenv("IPX_DEBUG_MAXCOLS")) maxcols = atoi(getenv("IPX_DEBUG_MAXCOLS"));   // timing experiments only (breaks score2)
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(b.cigar_cursor, 1);
     be.zero_u32(ws.tb_list_n, 8);

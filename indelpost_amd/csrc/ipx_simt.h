@@ -18,6 +18,7 @@ typedef uint32_t pk16; // two 16-bit DP cells: lo half = even alignment slot, hi
 #define IPX_KERNEL
 #define IPX_KERNEL_WAVE
 #define IPX_DEV static inline
+#define IPX_HD static inline
 #define IPX_UNROLL
 #define IPX_RESTRICT
 namespace ipx_emu {
@@ -66,6 +67,9 @@ IPX_DEV pk16 pk_minu(pk16 a, pk16 b) {
     return l | (h << 16);
 }
 IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return (v >> off) & ((1u << width) - 1u); }
+// (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b)
+IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
+IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 
@@ -77,6 +81,7 @@ IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 #define IPX_KERNEL __global__
 #define IPX_KERNEL_WAVE __global__ __launch_bounds__(64)   // block = one wavefront: the whole VGPR file is available
 #define IPX_DEV __device__ __forceinline__
+#define IPX_HD __host__ __device__ inline
 #define IPX_UNROLL _Pragma("unroll")
 #define IPX_RESTRICT __restrict__
 #define IPX_TID ((int)threadIdx.x)
@@ -119,6 +124,9 @@ IPX_DEV pk16 pk_subus(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_sub_
 IPX_DEV pk16 pk_max(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_max(IPX_S2(a), IPX_S2(b))); }            // v_pk_max_i16
 IPX_DEV pk16 pk_minu(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_min(IPX_U2(a), IPX_U2(b))); }           // v_pk_min_u16
 IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
+// (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b): one v_perm_b32
+IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 #endif
