@@ -20,12 +20,13 @@
 //     before that column, so the un-saturated 16-bit result is bit-identical up to the exit.
 //   * the striped column state (H, E, and the column saved at the best score) lives in registers:
 //     segment j of the reference = register j, fully unrolled.
-//   * the substitution profile of the tile's reads is staged in LDS as int16 rows
-//     [letter][half][lane][j]: a lane's scores for one letter are CONTIGUOUS, so a column needs a few
-//     64-bit LDS reads per lane instead of one read per segment (byte-wide LDS reads turned out to
-//     be the bottleneck: ~16 cycles per wave instruction).  Row length is 8*(odd) bytes, which makes
-//     the 32-lane ds_read_b64 groups bank-conflict free.  The window bytes are streamed four
-//     columns at a time from 4-byte aligned, re-packed windows.
+//   * the substitution profile of the tile's reads is staged in LDS as int8 [letter][j][lane][half]
+//     (12 KB per wave at 150 bp): per column each lane fetches its two profile bytes per segment,
+//     bank-conflict free by construction.  Keeping the per-wave LDS footprint small matters more than
+//     wide reads here: a wave issues one instruction per ~4 cycles, so a SIMD needs >= 2-3 resident
+//     waves (8-12 per CU) to approach its issue rate.  For the same reason the per-column maxima go
+//     to a small per-block global scratch (L2-resident) instead of LDS.  The window bytes are
+//     streamed four columns at a time from 4-byte aligned, re-packed windows.
 //   * lazy-F keeps the reference's data-dependent exit per read: a read that would `goto end`
 //     gets its F zeroed, the wave leaves the loop when every read is out.
 #pragma once
@@ -35,15 +36,6 @@
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-// bytes of one lane's profile row: 2*S rounded up to 8*(odd) -> conflict-free ds_read_b64
-IPX_HD constexpr int ipx_prof_row_bytes(int S)
-{
-    int q = (2 * S + 7) / 8;
-    if (q < 1) q = 1;
-    if ((q & 1) == 0) ++q;
-    return 8 * q;
-}
-
 template <int W> IPX_DEV pk16 group_or(pk16 x)
 {
     x |= xl_xor1(x);
@@ -241,7 +233,7 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          !EXACT (long reads): S <= SMAX is read per tile and every segment step is branch-guarded
 //   REV  = reverse pass (reversed read prefix vs window prefix walked right to left, ssw.c:875-886)
 // Block = one wavefront (64 threads); grid-stride over the tiles of classes [cls_lo, cls_hi].
-// Dynamic LDS: profile 640*rowbytes(SMAX) B | column maxima 4*G*maxcols B (forward only) | matrix 32 B
+// Dynamic LDS: profile 640*SMAX B | matrix 32 B.   Global: column maxima, 4*G*maxcols B per block (forward only)
 // ------------------------------------------------------------------------------------------------
 //   LOW  = first stage of the 8-bit forward pass: lazy-F carries that could meet the reference's
 //          signed-byte exit test (>= 128+gapE) are dropped instead of stepped.  The result is a lower
@@ -256,11 +248,10 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
     constexpr bool BYTE = (W == 16);
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
-    constexpr int ROWB = ipx_prof_row_bytes(SMAX);     // LDS is carved for SMAX; the row stride follows the tile's S
-    constexpr int QMAX = ROWB / 8;
     unsigned char *lds = IPX_LDS_BASE;
-    uint32_t *maxcol = (uint32_t *)(lds + 640 * ROWB);
-    int8_t *matl = (int8_t *)(lds + 640 * ROWB + (REV ? 0 : 4 * G * maxcols));
+    int8_t *prof = (int8_t *)lds;                                  // [5][S][64][2]
+    int8_t *matl = (int8_t *)(lds + 640 * SA);
+    uint32_t *maxcol = b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);   // this block's column maxima
 
     if (lane < 25) matl[lane] = b.mat[lane];
     IPX_SYNC();
@@ -329,21 +320,19 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             D4 = pk_make(d[0][2], d[1][2]); D8 = pk_make(d[0][3], d[1][3]);
         }
 
-        // ---- stage the tile's query profile in LDS: int16 [5 letters][2 halves][64 lanes][rowb/2] ----
-        const int rowb = EXACT ? ROWB : ipx_prof_row_bytes(S);
-        const int Q = rowb / 8;                                    // 64-bit reads per lane, letter and half
+        // ---- stage the tile's query profile in LDS: int8 [5 letters][S][64 lanes][2 halves] ------------
         IPX_SYNC();   // previous tile's finalisation reads are done
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
-            for (int j = 0; j < 4 * Q; ++j) {
+            for (int j = 0; j < S; ++j) {
                 const int r = j + l * S;                           // striped row (ssw.c:178-185)
                 int base = -1;
-                if (j < S && r < L[h]) {
+                if (r < L[h]) {
                     base = REV ? rd[h][L[h] - 1 - r] : rd[h][r];   // reverse pass: seq_reverse (ssw.c:774-785)
                     if ((unsigned)base > 4u) base = 4;
                 }
                 for (int c = 0; c < 5; ++c)
-                    *(int16_t *)(lds + ((c * 2 + h) * 64 + lane) * rowb + 2 * j) = base >= 0 ? (int16_t)matl[c * 5 + base] : (int16_t)0;
+                    prof[((c * S + j) * 64 + lane) * 2 + h] = base >= 0 ? matl[c * 5 + base] : (int8_t)0;
             }
         }
         IPX_SYNC();
@@ -402,14 +391,8 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                     Hlast &= ~fresh;
                 }
             }
-            // this column's profile rows: Q 64-bit reads per half
-            const uint64_t *pr0 = (const uint64_t *)(lds + (((int)c[0] * 2 + 0) * 64 + lane) * rowb);
-            const uint64_t *pr1 = (const uint64_t *)(lds + (((int)c[1] * 2 + 1) * 64 + lane) * rowb);
-            uint64_t R0[QMAX], R1[QMAX];
-            IPX_UNROLL
-            for (int k = 0; k < QMAX; ++k) {
-                if (k < Q) { R0[k] = pr0[k]; R1[k] = pr1[k]; }
-            }
+            const int8_t *pa0 = prof + ((int)c[0] * S * 64 + lane) * 2;
+            const int8_t *pa1 = prof + ((int)c[1] * S * 64 + lane) * 2 + 1;
 
             // -- striped inner loop (ssw.c:274-299 / 480-504) -----------------------------------------
             pk16 vH = xl_row_shr1(Hlast);                         // _mm_slli_si128(pvHStore[segLen-1], 1|2)
@@ -418,9 +401,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             IPX_UNROLL
             for (int j = 0; j < SMAX; ++j) {
                 if (j < S) {
-                    const uint32_t plo = (uint32_t)(R0[j / 4] >> (32 * ((j / 2) & 1)));
-                    const uint32_t phi = (uint32_t)(R1[j / 4] >> (32 * ((j / 2) & 1)));
-                    const pk16 pp = (j & 1) ? pk_hi16_pair(plo, phi) : pk_lo16_pair(plo, phi);
+                    const pk16 pp = pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]);
                     pk16 h = pk_add_sat(vH, pp);
                     pk16 e = E[j];
                     h = pk_max(h, e);
@@ -526,7 +507,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         }
 
         // ---- finalisation ---------------------------------------------------------------------------
-        IPX_SYNC();   // column maxima written by lane 0 of each group are visible to the group
+        IPX_SYNC();   // column maxima written by lane 0 of each group (global scratch, same wave) are visible to the group
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
             // end position on the read: smallest striped row holding `best` in the saved column (ssw.c:340-349)

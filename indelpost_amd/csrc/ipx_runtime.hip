@@ -65,7 +65,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_next, tb_esc, tb0, tb1;
+    DevBuf perm, tb_list, tb_next, tb_esc, tb0, tb1, maxcol;
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -88,7 +88,7 @@ struct HipBackend {
     int dp_grid() const
     {
         int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
-        const int64_t cap = (int64_t)c->num_cu * 16;
+        const int64_t cap = (int64_t)c->num_cu * 12;       // ~ the resident wave count: per-block scratch stays L2-sized
         return (int)(g < cap ? g : cap);
     }
     int flat_grid(int64_t n) const
@@ -181,7 +181,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_next, &c->tb_esc, &c->tb0, &c->tb1})
+                      &c->tb_list, &c->tb_next, &c->tb_esc, &c->tb0, &c->tb1, &c->maxcol})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -302,6 +302,9 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb0_waves = w0; c->ws.tb1_waves = w1;
     if (carve_tb(c, c->tb0, s0, w0, &c->ws.tb0) || carve_tb(c, c->tb1, s1, w1, &c->ws.tb1)) return IPX_ERR_NO_DEVICE;
 
+    // column-maxima scratch of the forward passes: one region per DP block
+    if (c->maxcol.ensure((size_t)c->num_cu * 12 * 16 * (size_t)(d.max_ref_len + 8) * 4)) return IPX_ERR_NO_DEVICE;
+
     // small tables
     uint32_t *sm = c->small.as<uint32_t>();
     c->ws.plan.count = sm; sm += 128;
@@ -330,6 +333,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     b.res = c->res.as<IpxResult>();
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
     b.cigar_cursor = cursor; b.status = status;
+    b.maxcol_scratch = c->maxcol.as<uint32_t>();
     HIPCHK(hipStreamSynchronize(s));
     return IPX_OK;
 }

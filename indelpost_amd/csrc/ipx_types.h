@@ -66,6 +66,7 @@ struct IpxBatch {
     uint32_t *cigar_pool;
     uint32_t cigar_cap;         // capacity of cigar_pool in ops
     uint32_t *cigar_cursor;     // bump allocator (1 word)
+    uint32_t *maxcol_scratch;   // per DP block: column maxima of the tile in flight (forward passes)
     uint32_t *status;           // bit0: cigar pool exhausted, bit1: read too long, bit2: ref too long, bit3: traceback scratch exhausted
 };
 

@@ -205,6 +205,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
 
+    b.maxcol_scratch = zalloc<uint32_t>((size_t)be.dp_grid() * 16 * (size_t)(d.max_ref_len + 8));
     IpxWorkspace ws;
     memset(&ws, 0, sizeof ws);
     ws.plan.count = zalloc<uint32_t>(IPX_NUM_CLASSES);
@@ -245,6 +246,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
 
     *status_out = status;
     free(packed);
+    free(b.maxcol_scratch);
     free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
     free(ws.tb_list); free(ws.tb_next); free(ws.tb_esc); free(ws.tb_list_n); free(ws.tb_next_n);
     for (IpxTbScratch *t : {&ws.tb0, &ws.tb1}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
