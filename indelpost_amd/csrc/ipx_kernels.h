@@ -945,3 +945,204 @@ IPX_KERNEL_WAVE void k_traceback(IpxBatch b, const uint32_t *list, const uint32_
         b.res[jb] = r;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_tb_coop: banded_sw (ssw.c:588-772) for the few jobs whose band keeps doubling (large indels, or a
+// forward score the banded DP never reaches, so the band grows to the full rectangle).  ONE WAVEFRONT
+// PER JOB: the cells of a DP row are spread over the 64 lanes (one contiguous chunk per lane).  The only
+// dependency inside a row is the horizontal-gap chain f_j = max(H_{j-1} - gapO, f_{j-1} - gapE); with
+// A_j = max(E_j, 0, diag_j) ("H without F") it is the max-plus recurrence
+//     f_{j+1} = max(A_j - gapO, f_j - min(gapO, gapE)),
+// a prefix scan: each lane folds its chunk, the lane aggregates are scanned across the wave, and a
+// second sweep produces H, the direction planes (with the reference's tie-breaks, which need the actual
+// H_{j-1} and f_{j-1}; across a lane boundary they are handed over through LDS) and the new band row.
+// Band rows live in LDS, direction bytes (same encoding and linear cell index as k_traceback) in a
+// per-block global scratch; the trace back itself is sequential (lane 0).
+// Dynamic LDS: 64 B matrix | 128 ints hand-over | 4 * arrcap ints (h_b, e_b, h_c, new e_b)
+// ------------------------------------------------------------------------------------------------
+static inline int ipx_tbc_lds_bytes(int arrcap) { return 64 + 512 + 16 * arrcap; }
+
+IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t *list_n, uint8_t *dir_scratch,
+                               int64_t dircap, int arrcap, uint32_t *cig_scratch, int cigcap)
+{
+    const int lane = lane_id();
+    unsigned char *lds = IPX_LDS_BASE;
+    int8_t *matl = (int8_t *)lds;
+    int32_t *lastH = (int32_t *)(lds + 64);
+    int32_t *lastF = lastH + 64;
+    int32_t *hb = lastF + 64;
+    int32_t *eb = hb + arrcap;
+    int32_t *hc = eb + arrcap;
+    int32_t *en = hc + arrcap;
+    uint8_t *dir = dir_scratch + (int64_t)IPX_BID * dircap;
+    uint32_t *cig = cig_scratch + (int64_t)IPX_BID * cigcap;
+    if (lane < 25) matl[lane] = b.mat[lane];
+    IPX_SYNC();
+    const uint32_t n = *list_n;
+    const int NEG = -(1 << 29);
+
+    for (uint32_t item = (uint32_t)IPX_BID; item < n; item += (uint32_t)IPX_GDIM) {
+        const int64_t jb = list[item];
+        IpxResult r = b.res[jb];
+        const int rid = b.ref_id[jb];
+        const int fullRef = b.ref_len[rid];
+        const int8_t *refp = b.refs_packed + b.refp_off[rid];
+        const int8_t *readp = b.reads + b.read_off[jb] + r.read_begin1;
+        const int rb = r.ref_begin1;
+        const int refLen = r.ref_end1 - r.ref_begin1 + 1;             // ssw.c:897-899
+        const int readLen = r.read_end1 - r.read_begin1 + 1;
+        const int gapO = b.gap_open[jb], gapE = b.gap_ext[jb];
+        const int g = gapO < gapE ? gapO : gapE;
+        const int score = r.score1;
+        int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+        const int len = refLen > readLen ? refLen : readLen;
+        int mx = 0, width = 0, width_d = 0, extent = 0;
+        bool broken = false;
+        for (int q = lane; q < arrcap; q += 64) { hb[q] = 0; eb[q] = 0; hc[q] = 0; en[q] = 0; }
+        IPX_SYNC();
+
+        do {
+            width = bw * 2 + 3;
+            width_d = bw * 2 + 1;
+            const int64_t cells = (int64_t)width_d * (readLen > 0 ? readLen : 1);
+            if (width + 1 > arrcap || cells > dircap) { broken = true; break; }
+            for (int64_t q = extent + lane; q < cells; q += 64) dir[q] = 0;
+            if ((int)cells > extent) extent = (int)cells;
+            for (int j = 1 + lane; j < width - 1; j += 64) hb[j] = 0;                       // ssw.c:627
+            IPX_SYNC();
+            for (int i = 0; i < readLen; ++i) {
+                int beg = 0, end = refLen - 1;
+                if (i - bw > beg) beg = i - bw;
+                if (i + bw < end) end = i + bw;
+                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;                // ssw.c:632
+                const int x = beg;                                                         // band shift of row i
+                const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;                            // ... of row i-1
+                if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }   // ssw.c:633
+                IPX_SYNC();
+                int rc = readp[i];
+                if ((unsigned)rc > 4u) rc = 4;
+                const int ncell = end - beg + 1;
+                const int cp = (ncell + 63) / 64;                                          // cells per lane
+                const int c0 = lane * cp < ncell ? lane * cp : ncell;
+                const int c1 = c0 + cp < ncell ? c0 + cp : ncell;                          // this lane's chunk [c0, c1)
+                // sweep 1: fold the chunk into (dec, agg): f_out = max(f_in - dec, agg)
+                int agg = NEG;
+                for (int c = c0; c < c1; ++c) {
+                    const int j = beg + c, e = j - xp + 1;
+                    const int t1 = i == 0 ? -gapO : hb[e] - gapO;
+                    const int t2 = i == 0 ? -gapE : eb[e] - gapE;
+                    const int ev = t1 > t2 ? t1 : t2;
+                    const int ri = rb + j;
+                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    int a = hb[e - 1] + matl[rcode * 5 + rc];
+                    if (ev > a) a = ev;
+                    if (a < 0) a = 0;                                                      // A_j
+                    agg = (agg - g > a - gapO) ? agg - g : a - gapO;                       // F carried out after this cell
+                }
+                int dec = (c1 - c0) * g;
+                for (int sft = 1; sft < 64; sft <<= 1) {                                   // inclusive scan over lanes
+                    const int src = lane >= sft ? lane - sft : lane;
+                    const int pd = (int)xl_shfl((uint32_t)dec, src);
+                    const int pa = (int)xl_shfl((uint32_t)agg, src);
+                    if (lane >= sft) {
+                        const int cand = pa - dec;                                         // earlier block, then this one
+                        agg = cand > agg ? cand : agg;
+                        dec = dec + pd > (1 << 28) ? (1 << 28) : dec + pd;
+                    }
+                }
+                const int pdx = (int)xl_shfl((uint32_t)dec, lane > 0 ? lane - 1 : 0);
+                const int pax = (int)xl_shfl((uint32_t)agg, lane > 0 ? lane - 1 : 0);
+                // h_c[0] = 0 and f = 0 before the row's first cell -> the F entering cell 0 is max(-gapO, -gapE) = -g
+                int fcur = -g;
+                if (lane > 0) { const int a0 = -g - pdx; fcur = a0 > pax ? a0 : pax; }
+                // sweep 2: H, directions, new band rows
+                int hprev = 0, fprev = 0;                                                  // (H, F) of the cell to the left
+                for (int c = c0; c < c1; ++c) {
+                    const int j = beg + c, u = j - x + 1, e = j - xp + 1;
+                    const int t1 = i == 0 ? -gapO : hb[e] - gapO;                          // ssw.c:644-648
+                    const int t2 = i == 0 ? -gapE : eb[e] - gapE;
+                    const int ev = t1 > t2 ? t1 : t2;
+                    const int de = t1 > t2 ? 1 : 0;
+                    int df = 0;
+                    if (c > c0) df = (hprev - gapO > fprev - gapE) ? 1 : 0;                // ssw.c:650-653 (first cell: below)
+                    const int e1 = ev > 0 ? ev : 0;                                        // ssw.c:655-664
+                    const int f1 = fcur > 0 ? fcur : 0;
+                    const int tt1 = e1 > f1 ? e1 : f1;
+                    const int ri = rb + j;
+                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    const int tt2 = hb[e - 1] + matl[rcode * 5 + rc];
+                    const int hv = tt1 > tt2 ? tt1 : tt2;
+                    const int dh = tt1 <= tt2 ? 0 : (e1 > f1 ? 1 : 2);
+                    en[u] = ev;
+                    hc[u] = hv;
+                    if (hv > mx) mx = hv;
+                    dir[(int64_t)width_d * i + (j - x)] = (uint8_t)(0x80 | (dh << 2) | (df << 1) | de);
+                    hprev = hv; fprev = fcur;
+                    const int o1 = hv - gapO, o2 = fcur - gapE;
+                    fcur = o1 > o2 ? o1 : o2;
+                }
+                lastH[lane] = hprev; lastF[lane] = fprev;                                  // hand-over to the next lane
+                IPX_SYNC();
+                if (c0 < c1) {                                                             // F direction of the chunk's first cell
+                    int hl = 0, fl = 0;                                                    // before the row: h_c[0] = 0, f = 0
+                    if (c0 > 0) { hl = lastH[lane - 1]; fl = lastF[lane - 1]; }
+                    if (hl - gapO > fl - gapE) dir[(int64_t)width_d * i + c0] |= 2;
+                }
+                for (int uu = 1 + lane; uu <= ncell; uu += 64) { hb[uu] = hc[uu]; eb[uu] = en[uu]; }   // ssw.c:666; e_b as in place
+                IPX_SYNC();
+            }
+            mx = (int)wave_umax((uint32_t)mx);                                             // every lane saw only its own cells
+            bw *= 2;
+        } while (mx < score && bw <= len);                                                // ssw.c:669
+        if (broken) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH); continue; }
+        bw /= 2;
+
+        // ---- trace back (ssw.c:673-751), lane 0 ----
+        IPX_SYNC();
+        if (lane == 0) {
+            int i = readLen - 1, j = refLen - 1, e = 0, lcnt = 0, plane = 2, op = 0, prev = 0;
+            bool fail = false, full = false;
+            while (i >= 0 && j > 0) {
+                const int x = i - bw > 0 ? i - bw : 0;
+                const int64_t cell = (int64_t)width_d * i + (j - x);
+                int code = 0;
+                if (cell >= 0 && cell < extent) {
+                    const int v = dir[cell];
+                    if (v & 0x80) {
+                        const int de = 2 + (v & 1), df = 4 + ((v >> 1) & 1), dh = (v >> 2) & 3;
+                        code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
+                    }
+                }
+                if (code == 1) { --i; --j; plane = 2; op = 0; }
+                else if (code == 2) { --i; plane = 0; op = 1; }
+                else if (code == 3) { --i; plane = 2; op = 1; }
+                else if (code == 4) { --j; plane = 1; op = 2; }
+                else if (code == 5) { --j; plane = 2; op = 2; }
+                else { fail = true; break; }
+                if (op == prev) ++e;
+                else {
+                    ++lcnt;
+                    if (lcnt + 2 > cigcap) { full = true; break; }
+                    cig[lcnt - 1] = ((uint32_t)e << 4) | (uint32_t)prev;
+                    prev = op;
+                    e = 1;
+                }
+            }
+            if (full) atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH);
+            else if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; }                 // ssw.c:911
+            else {
+                if (op == 0) { ++lcnt; cig[lcnt - 1] = ((uint32_t)(e + 1) << 4); }         // ssw.c:734-751
+                else { lcnt += 2; cig[lcnt - 2] = ((uint32_t)e << 4) | (uint32_t)op; cig[lcnt - 1] = (1u << 4); }
+                const uint32_t off = atomic_add_u32(b.cigar_cursor, (uint32_t)lcnt);
+                if (off + (uint32_t)lcnt > b.cigar_cap) atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL);
+                else {
+                    for (int k = 0; k < lcnt; ++k) b.cigar_pool[off + k] = cig[lcnt - 1 - k];   // reverse (ssw.c:754-762)
+                    r.cigar_off = off;
+                    r.cigar_len = (uint16_t)lcnt;
+                    b.res[jb] = r;
+                }
+            }
+        }
+        IPX_SYNC();
+    }
+}

@@ -145,8 +145,10 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
 #undef IPX_TBF_LAUNCH
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 0), k_traceback, ws.tb0_waves, 64, 64, b, (const uint32_t *)ws.tb_esc,
                       (const uint32_t *)ws.tb_esc_n, ws.tb0, ws.tb_next, ws.tb_next_n);
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_traceback, ws.tb1_waves, 64, 64, b, (const uint32_t *)ws.tb_next,
-                      (const uint32_t *)ws.tb_next_n, ws.tb1, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            // what still does not fit (wide bands): one wavefront per job
+            be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_tb_coop, ws.tb1_waves, 64, ipx_tbc_lds_bytes(ws.tb1.arrcap), b,
+                      (const uint32_t *)ws.tb_next, (const uint32_t *)ws.tb_next_n, ws.tb1.dir, (int64_t)ws.tb1.dircap,
+                      ws.tb1.arrcap, ws.tb1.cig, ws.tb1.cigcap);
         }
     }
 }
@@ -173,4 +175,9 @@ static inline IpxTbSizing ipx_tb1_sizing(const IpxDims &d)
 static inline size_t ipx_tb_bytes_per_wave(const IpxTbSizing &s)
 {
     return 64ull * (3ull * 4ull * (size_t)s.arrcap + (size_t)s.dircap + 4ull * (size_t)s.cigcap);
+}
+// the one-wave-per-job kernel needs direction bytes and CIGAR runs for ONE job per block
+static inline size_t ipx_tbc_bytes_per_block(const IpxTbSizing &s)
+{
+    return (((size_t)s.dircap + 15) & ~(size_t)15) + 4ull * (size_t)s.cigcap + 16;
 }

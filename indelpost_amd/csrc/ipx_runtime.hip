@@ -296,11 +296,16 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     if (w0 > c->num_cu * 2) w0 = c->num_cu * 2;          // only what the LDS-resident kernel hands over
     const size_t lim0 = 512ull << 20;
     while (w0 > 1 && ipx_tb_bytes_per_wave(s0) * (size_t)w0 > lim0) w0 /= 2;
-    int w1 = 32;
+    int w1 = c->num_cu * 2;                                  // one job per block in k_tb_coop
     const size_t lim1 = 1024ull << 20;
-    while (w1 > 1 && ipx_tb_bytes_per_wave(s1) * (size_t)w1 > lim1) w1 /= 2;
+    while (w1 > 1 && ipx_tbc_bytes_per_block(s1) * (size_t)w1 > lim1) w1 /= 2;
     c->ws.tb0_waves = w0; c->ws.tb1_waves = w1;
-    if (carve_tb(c, c->tb0, s0, w0, &c->ws.tb0) || carve_tb(c, c->tb1, s1, w1, &c->ws.tb1)) return IPX_ERR_NO_DEVICE;
+    if (carve_tb(c, c->tb0, s0, w0, &c->ws.tb0)) return IPX_ERR_NO_DEVICE;
+    if (c->tb1.ensure(ipx_tbc_bytes_per_block(s1) * (size_t)w1)) return IPX_ERR_NO_DEVICE;
+    memset(&c->ws.tb1, 0, sizeof c->ws.tb1);
+    c->ws.tb1.arrcap = s1.arrcap; c->ws.tb1.dircap = (int32_t)(((size_t)s1.dircap + 15) & ~(size_t)15); c->ws.tb1.cigcap = s1.cigcap;
+    c->ws.tb1.dir = c->tb1.as<uint8_t>();
+    c->ws.tb1.cig = (uint32_t *)(c->tb1.as<char>() + (size_t)c->ws.tb1.dircap * (size_t)w1);
 
     // column-maxima scratch of the forward passes: one region per DP block
     if (c->maxcol.ensure((size_t)c->num_cu * 12 * 16 * (size_t)(d.max_ref_len + 8) * 4)) return IPX_ERR_NO_DEVICE;

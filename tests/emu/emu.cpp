@@ -240,7 +240,12 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
         return t;
     };
     ws.tb0 = mk(s0, ws.tb0_waves);
-    ws.tb1 = mk(s1, ws.tb1_waves);
+    ws.tb1_waves = 2;
+    memset(&ws.tb1, 0, sizeof ws.tb1);
+    ws.tb1.arrcap = s1.arrcap; ws.tb1.dircap = s1.dircap; ws.tb1.cigcap = s1.cigcap;
+    ws.tb1.dir = (uint8_t *)malloc((size_t)s1.dircap * ws.tb1_waves + 64);
+    ws.tb1.cig = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)s1.cigcap * ws.tb1_waves + 64);
+    memset(ws.tb1.dir, 0x5A, (size_t)s1.dircap * ws.tb1_waves);
 
     ipx_run_pipeline(be, b, ws, d);
 
@@ -249,6 +254,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     free(b.maxcol_scratch);
     free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
     free(ws.tb_list); free(ws.tb_next); free(ws.tb_esc); free(ws.tb_list_n); free(ws.tb_next_n);
-    for (IpxTbScratch *t : {&ws.tb0, &ws.tb1}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
+    for (IpxTbScratch *t : {&ws.tb0}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
+    free(ws.tb1.dir); free(ws.tb1.cig);
     return 0;
 }
