@@ -132,12 +132,16 @@ IPX_DEV int plan_class(const IpxBatch &b, int pass, int64_t i)
     const IpxResult r = b.res[i];
     int L, lanes, ncol;
     switch (pass) {
+    case IPX_PASS_WORD_FIRST:
+        if (b.score_size != 2 || r.mode != IPX_MODE_PENDING || b.word_first_len <= 0 || readLen < b.word_first_len) return -1;
+        L = readLen; lanes = 8; ncol = refLen;
+        break;
     case IPX_PASS_BYTE_FWD:
-        if (b.score_size == 1 || r.mode != IPX_MODE_PENDING) return -1;
+        if (b.score_size == 1 || (r.mode != IPX_MODE_PENDING && r.mode != IPX_MODE_NEED_BYTE_CHECK)) return -1;
         L = readLen; lanes = 16; ncol = refLen;
         break;
     case IPX_PASS_BYTE_FWD_EXACT:
-        if (r.mode != IPX_MODE_NEED_BYTE_EXACT) return -1;
+        if (r.mode != IPX_MODE_NEED_BYTE_EXACT && r.mode != IPX_MODE_NEED_BYTE_EXACT_W) return -1;
         L = readLen; lanes = 16; ncol = refLen;
         break;
     case IPX_PASS_WORD_FWD:
@@ -240,7 +244,7 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          bound of the exact pass, so "overflow" is certain; reads that neither overflowed nor lost
 //          a carry are exact; the rest are re-run by the exact instantiation (IPX_MODE_NEED_BYTE_EXACT).
 template <int W, int SMAX, bool REV, bool EXACT, bool LOW>
-IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols)
+IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
@@ -541,13 +545,16 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 const bool lost = LOW && ((group_or<W>(dropped) >> (16 * h)) & 0xFFFFu) != 0;   // (all lanes take part)
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
+                    // a 16-bit result may already sit in the record (IPX_PASS_WORD_FIRST): an overflowing 8-bit pass keeps it
+                    const bool has_word = r.mode == IPX_MODE_NEED_BYTE_CHECK || r.mode == IPX_MODE_NEED_BYTE_EXACT_W;
                     if (BYTE && overflow) {
-                        if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }                 // -> 16-bit pass (ssw.c:844-847)
+                        if (has_word) r.mode = IPX_MODE_WORD;
+                        else if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }            // -> 16-bit pass (ssw.c:844-847)
                         else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851
                     } else if (lost) {
-                        r.mode = IPX_MODE_NEED_BYTE_EXACT;                                                     // lower bound only: exact 8-bit pass decides
+                        r.mode = has_word ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_EXACT;             // lower bound only: exact 8-bit pass decides
                     } else {
-                        r.mode = BYTE ? IPX_MODE_BYTE : IPX_MODE_WORD;
+                        r.mode = BYTE ? IPX_MODE_BYTE : (pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD);
                         r.score1 = (uint16_t)bh;
                         r.ref_end1 = eref;
                         r.read_end1 = end_read;
@@ -568,6 +575,39 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prove_overflow: the reference always runs the 8-bit pass first and only then the 16-bit pass
+// (ssw.c:842-847).  For reads that will almost surely overflow we run the 16-bit pass first
+// (IPX_PASS_WORD_FIRST) and then try to PROVE, without the 8-bit pass, that it overflows: every cell of
+// the 8-bit matrix is >= the ungapped local score of its diagonal (H = max(diag + P, E, F) >= diag + P
+// and >= 0, up to the first saturation), so if the best ungapped run on the diagonal through the
+// 16-bit end point reaches 255-bias, the 8-bit pass is certain to leave with 255 and the 16-bit
+// result is the answer.  One lane per read, O(readLen).  Unproven reads take the 8-bit pass as usual.
+// ------------------------------------------------------------------------------------------------
+IPX_KERNEL void k_prove_overflow(IpxBatch b)
+{
+    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
+        IpxResult r = b.res[i];
+        if (r.mode != IPX_MODE_WORD_UNPROVEN) continue;
+        const int8_t *rd = b.reads + b.read_off[i];
+        const int rid = b.ref_id[i];
+        const int8_t *rf = b.refs_packed + b.refp_off[rid];
+        const int m = r.ref_end1 < r.read_end1 ? r.ref_end1 : r.read_end1;   // cells on the diagonal up to the end point
+        const int cap = 255 - b.bias;
+        int u = 0;
+        bool proven = false;
+        for (int k = m; k >= 0 && !proven; --k) {
+            int a = rd[r.read_end1 - k], c = rf[r.ref_end1 - k];
+            if ((unsigned)a > 4u) a = 4;
+            u += b.mat[c * 5 + a];
+            if (u < 0) u = 0;
+            if (u >= cap) proven = true;
+        }
+        r.mode = proven ? IPX_MODE_WORD : IPX_MODE_NEED_BYTE_CHECK;
+        b.res[i] = r;
     }
 }
 

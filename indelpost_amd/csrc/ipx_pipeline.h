@@ -42,7 +42,7 @@ static inline void ipx_dims_add_read(IpxDims &d, int len)
 // kernel classes for per-kernel timing (ipx_runtime.hip records HIP events around each launch)
 enum {
     IPX_K_INIT = 0, IPX_K_PLAN, IPX_K_BYTE_FWD, IPX_K_WORD_FWD, IPX_K_BYTE_REV, IPX_K_WORD_REV,
-    IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_NUM
+    IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_WORD_FIRST, IPX_K_PROVE, IPX_K_NUM
 };
 
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols)
@@ -58,12 +58,12 @@ static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols)
 #define IPX_SUB_GENERIC 65
 
 template <class BE, int W, bool REV, bool LOW>
-static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int S, int maxcols, int kclass)
+static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int S, int maxcols, int kclass, int pass)
 {
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
         be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW>, be.dp_grid(), 64,                          \
-                  ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols);                                \
+                  ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass);                                \
         break;
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
@@ -79,19 +79,19 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 // forward passes launch exactly the segLen classes that occur among the reads (known on the host);
 // reverse passes align a read PREFIX, so every class up to the longest read may occur
 template <class BE, int W, bool REV, bool LOW>
-static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass)
+static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass)
 {
     int top = -1;
     for (int c = 0; c < IPX_NUM_CLASSES; ++c) if (has[c]) top = c;
     bool generic = false;
     for (int c = 0; c <= top; ++c) {
         if (!REV && !has[c]) continue;
-        if (c <= IPX_MAX_EXACT) ipx_launch_dp_class<BE, W, REV, LOW>(be, b, p, c, maxcols, kclass);
+        if (c <= IPX_MAX_EXACT) ipx_launch_dp_class<BE, W, REV, LOW>(be, b, p, c, maxcols, kclass, pass);
         else generic = true;
     }
     if (generic)
         be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.dp_grid(), 64,
-                  ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, IPX_MAX_EXACT + 1, IPX_MAX_SEG, maxcols);
+                  ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, IPX_MAX_EXACT + 1, IPX_MAX_SEG, maxcols, pass);
 }
 
 template <class BE>
@@ -113,25 +113,31 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     be.zero_u32(ws.tb_list_n, 8);
     be.zero_u32(ws.tb_next_n, 1);
 
+    if (b.score_size == 2 && b.word_first_len > 0 && d.max_read_len >= b.word_first_len) {
+        // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
+        ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_FIRST, 16);
+        ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST);
+        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs), 256, 0, b);
+    }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD, 8);
-        ipx_launch_dp<BE, 16, false, true>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD);
+        ipx_launch_dp<BE, 16, false, true>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD, IPX_PASS_BYTE_FWD);
         // reads whose lower-bound stage was inconclusive: exact 8-bit pass
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD_EXACT, 8);
-        ipx_launch_dp<BE, 16, false, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD_X);
+        ipx_launch_dp<BE, 16, false, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD_X, IPX_PASS_BYTE_FWD_EXACT);
     }
     if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_FWD, 16);
-        ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FWD);
+        ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD);
     }
     if (b.flag != 0) {                                           // begin position (ssw.c:872-886)
         if (b.score_size != 1) {
             ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_REV, 8);
-            ipx_launch_dp<BE, 16, true, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_REV);
+            ipx_launch_dp<BE, 16, true, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV);
         }
         if (b.score_size != 0) {
             ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_REV, 16);
-            ipx_launch_dp<BE, 8, true, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV);
+            ipx_launch_dp<BE, 8, true, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
@@ -151,6 +157,19 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                       ws.tb1.arrcap, ws.tb1.cig, ws.tb1.cigcap);
         }
     }
+}
+
+
+// reads at least this long are very likely to overflow the 8-bit pass (their best possible score is
+// >= 1.4x the overflow threshold): they take the 16-bit pass first.  Any value is correct; it only
+// moves work between passes.
+static inline int ipx_word_first_len(const int8_t *mat, int bias)
+{
+    int mx = 0;
+    for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
+    if (mx <= 0) return 0;
+    const int cap = 255 - bias;
+    return (cap * 14 / 10 + mx - 1) / mx;
 }
 
 // scratch sizing shared by both back-ends -------------------------------------------------------

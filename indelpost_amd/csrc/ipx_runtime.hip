@@ -135,7 +135,7 @@ struct HipBackend {
 };
 
 static const char *k_names[IPX_K_NUM] = {"init", "plan", "dp_byte_fwd", "dp_word_fwd", "dp_byte_rev",
-                                         "dp_word_rev", "tb_list", "traceback", "pack_refs", "dp_byte_fwd_exact"};
+                                         "dp_word_rev", "tb_list", "traceback", "pack_refs", "dp_byte_fwd_exact", "dp_word_first", "prove_overflow"};
 
 extern "C" {
 
@@ -349,6 +349,7 @@ int ipx_run(ipx_ctx *c)
     HIPCHK(hipSetDevice(c->device));
     IpxBatch &b = c->batch;
     memcpy(b.mat, c->mat, 25);
+    b.word_first_len = getenv("IPX_NO_WORD_FIRST") ? 0 : ipx_word_first_len(c->mat, c->bias);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
@@ -441,7 +442,7 @@ const char *ipx_kernel_class_name(int k)
     static thread_local char buf[64];
     if (k < 0 || k >= IPX_NUM_KEYS) return "";
     const int kc = k / 128, sub = k % 128;
-    if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X) {
+    if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X || kc == IPX_K_WORD_FIRST) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
     } else if (kc == IPX_K_TRACEBACK) { if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }

@@ -26,6 +26,9 @@ enum {
     IPX_MODE_FAIL = 2,       // reference would return NULL (8-bit only profile overflowed, ssw.c:848-851)
     IPX_MODE_NEED_WORD = 3,  // 8-bit pass overflowed, 16-bit pass still to run
     IPX_MODE_NEED_BYTE_EXACT = 4,  // 8-bit lower-bound stage inconclusive, exact 8-bit pass still to run
+    IPX_MODE_WORD_UNPROVEN = 5,    // 16-bit result computed FIRST; 8-bit overflow not yet established
+    IPX_MODE_NEED_BYTE_CHECK = 6,  // ... and not provable from the diagonal: the 8-bit pass decides
+    IPX_MODE_NEED_BYTE_EXACT_W = 7,// as NEED_BYTE_EXACT, with a 16-bit result already in the record
     IPX_MODE_PENDING = 255,  // not processed yet
 };
 
@@ -35,7 +38,8 @@ enum {
     IPX_PASS_BYTE_REV = 2,
     IPX_PASS_WORD_REV = 3,
     IPX_PASS_BYTE_FWD_EXACT = 4,
-    IPX_NUM_PASSES = 5,
+    IPX_PASS_WORD_FIRST = 5,      // 16-bit forward pass BEFORE the 8-bit one, for reads that will almost surely overflow
+    IPX_NUM_PASSES = 6,
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels
@@ -58,6 +62,7 @@ struct IpxBatch {
     const int32_t *mask_len;    // n_jobs or nullptr -> max(15, readLen/2)  (sswpy.pyx:209-211)
     int8_t mat[25];             // 5x5 substitution matrix (sswpy.pyx:306-336)
     int32_t bias;               // |min(mat)| (ssw.c:795-799)
+    int32_t word_first_len;     // reads at least this long take the 16-bit pass first (0 = never); speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)
     uint16_t filters;
