@@ -132,6 +132,7 @@ int ipx_num_kernel_classes(void);
 const char *ipx_kernel_class_name(int k);
 int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches);   /* arrays of ipx_num_kernel_classes() */
 float ipx_last_run_ms(ipx_ctx *c);            /* events around the last ipx_run, valid after ipx_sync */
+int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out9);   /* traceback routing of the last run (diagnostic) */
 
 /* deterministic synthetic workload of SURVEY.md section 8d (xorshift64), host side:
  * one window of `wl` codes and n reads of `rl` codes; returns the final generator state */

@@ -246,6 +246,12 @@ class GpuAligner:
                 out[name] = (t + float(ms[i]), c + int(cnt[i]))
         return out
 
+    def traceback_routing(self):
+        """jobs per first band width 1..7, jobs handed to the general kernel, jobs handed to the wide-band kernel"""
+        out = np.zeros(9, np.uint32)
+        self._check(self._L.ipx_debug_tb_counts(self._ctx, _p(out)), "ipx_debug_tb_counts")
+        return out.tolist()
+
     def last_run_ms(self):
         return float(self._L.ipx_last_run_ms(self._ctx))
 

@@ -296,7 +296,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     if (w0 > c->num_cu * 2) w0 = c->num_cu * 2;          // only what the LDS-resident kernel hands over
     const size_t lim0 = 512ull << 20;
     while (w0 > 1 && ipx_tb_bytes_per_wave(s0) * (size_t)w0 > lim0) w0 /= 2;
-    int w1 = c->num_cu * 2;                                  // one job per block in k_tb_coop
+    int w1 = c->num_cu * 8;                                  // one job per block in k_tb_coop (latency-bound: many blocks)
     const size_t lim1 = 1024ull << 20;
     while (w1 > 1 && ipx_tbc_bytes_per_block(s1) * (size_t)w1 > lim1) w1 /= 2;
     c->ws.tb0_waves = w0; c->ws.tb1_waves = w1;
@@ -456,6 +456,17 @@ int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches)
     return IPX_OK;
 }
 float ipx_last_run_ms(ipx_ctx *c) { return c ? c->last_run_ms : 0.f; }
+
+// diagnostic: traceback routing of the last run -- out[0..6] jobs per first band width 1..7, out[7] jobs
+// handed to the general kernel, out[8] jobs handed on to the one-wave-per-job kernel
+int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out)
+{
+    if (!c || !out || !c->ws.tb_list_n) return IPX_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(out, c->ws.tb_list_n, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out + 8, c->ws.tb_next_n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return IPX_OK;
+}
 
 // ---- synthetic workload generator, host side ----------------------------------------
 static inline uint32_t xs_next(uint64_t &s)
