@@ -332,7 +332,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 const int r = j + l * S;                           // striped row (ssw.c:178-185)
                 int base = -1;
                 if (r < L[h]) {
-                    base = REV ? rd[h][L[h] - 1 - r] : rd[h][r];   // reverse pass: seq_reverse (ssw.c:774-785)
+                    base = load_stream_i8(REV ? rd[h] + (L[h] - 1 - r) : rd[h] + r);   // reverse pass: seq_reverse (ssw.c:774-785)
                     if ((unsigned)base > 4u) base = 4;
                 }
                 for (int c = 0; c < 5; ++c)
@@ -587,12 +587,26 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
 // 16-bit end point reaches 255-bias, the 8-bit pass is certain to leave with 255 and the 16-bit
 // result is the answer.  One lane per read, O(readLen).  Unproven reads take the 8-bit pass as usual.
 // ------------------------------------------------------------------------------------------------
-IPX_KERNEL void k_prove_overflow(IpxBatch b)
+IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap)
 {
-    for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
+    // 64 consecutive jobs per wavefront: their reads are contiguous in HBM, so the wave copies them into
+    // LDS with coalesced loads and every lane then walks its own read there (the per-lane backwards byte
+    // walk straight from HBM fetched ~6 KB per read).  Batches that do not fit `lds_cap` fall back to HBM.
+    const int lane = lane_id();
+    int8_t *stage = (int8_t *)IPX_LDS_BASE;
+    const int64_t nb = (b.n_jobs + 63) / 64;
+    for (int64_t blk = IPX_BID; blk < nb; blk += IPX_GDIM) {
+        const int64_t i0 = blk * 64, i = i0 + lane;
+        const int64_t i1 = i0 + 64 < b.n_jobs ? i0 + 64 : b.n_jobs;
+        const int64_t lo = b.read_off[i0], hi = b.read_off[i1];
+        const bool staged = hi - lo <= (int64_t)lds_cap;
+        IPX_SYNC();
+        if (staged) for (int64_t q = lo + lane; q < hi; q += 64) stage[q - lo] = load_stream_i8(b.reads + q);
+        IPX_SYNC();
+        if (i >= b.n_jobs) continue;
         IpxResult r = b.res[i];
         if (r.mode != IPX_MODE_WORD_UNPROVEN) continue;
-        const int8_t *rd = b.reads + b.read_off[i];
+        const int8_t *rd = staged ? stage + (b.read_off[i] - lo) : b.reads + b.read_off[i];
         const int rid = b.ref_id[i];
         const int8_t *rf = b.refs_packed + b.refp_off[rid];
         const int m = r.ref_end1 < r.read_end1 ? r.ref_end1 : r.read_end1;   // cells on the diagonal up to the end point

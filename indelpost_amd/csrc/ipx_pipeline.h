@@ -117,7 +117,11 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_FIRST, 16);
         ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST);
-        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs), 256, 0, b);
+        {
+            int cap = 64 * d.max_read_len;                        // one wave's reads
+            if (cap > 60 * 1024) cap = 60 * 1024;
+            be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, cap + 64, b, cap);
+        }
     }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD, 8);

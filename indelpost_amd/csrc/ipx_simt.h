@@ -70,6 +70,7 @@ IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return (v >> o
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b)
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
 IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
+IPX_DEV int8_t load_stream_i8(const int8_t *p) { return *p; }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 
@@ -127,6 +128,8 @@ IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __built
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b): one v_perm_b32
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// read-once data (the read letters): keep it out of the way of the L2-resident per-block scratch
+IPX_DEV int8_t load_stream_i8(const int8_t *p) { return __builtin_nontemporal_load(p); }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 #endif
