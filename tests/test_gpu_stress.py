@@ -84,3 +84,63 @@ def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, capfd):
     first = np.flatnonzero(dp_fields_bad | bad_flag | bad_cig | (defined & bad))
     assert len(first) == 0, "scoring %s: %d jobs differ, first %d: gpu %s cpu %s" % (
         scoring, len(first), first[0], rec[first[0]], exp[first[0]])
+
+
+def _windows_reads(n_windows, reads_per_window, rls, wl_lo, wl_hi):
+    """SURVEY 8d generator (xorshift64 windows + error-model reads) for several windows / read lengths."""
+    from indelpost_amd import _lib, synth
+    L = _lib.lib()
+    st = synth.SEED
+    rng = np.random.default_rng(5)
+    refs, reads, rid = [], [], []
+    for w in range(n_windows):
+        wl = int(rng.integers(wl_lo, wl_hi + 1))
+        ref = np.zeros(wl, np.int8)
+        st = L.ipx_synth_window(st, ref.ctypes.data, wl)
+        refs.append(ref)
+        per = max(1, reads_per_window // len(rls))
+        for rl in rls:
+            rl = min(rl, wl)
+            buf = np.zeros(per * rl, np.int8)
+            st = L.ipx_synth_reads(st, ref.ctypes.data, wl, buf.ctypes.data, per, rl)
+            reads.extend(buf.reshape(per, rl))
+            rid.extend([w] * per)
+    return reads, refs, rid
+
+
+def _check_all(gpu, oracle_mod, jobs, scoring, capfd):
+    from oracle.oracle import cpu_batch_results, fnv1a_ops
+    be = oracle_mod.Backend("reference" if oracle_mod.have_reference() else "port")
+    exp = cpu_batch_results(be, jobs, oracle_mod.dna_matrix(*scoring), len(os.sched_getaffinity(0)))
+    capfd.readouterr()
+    gpu.set_scoring(*scoring)
+    res = gpu.align(jobs)
+    rec = res.records
+    for f in ("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2", "cigar_len", "flag"):
+        assert (rec[f] == exp[f]).all(), f
+    n = jobs.n_jobs
+    hashes = np.array([fnv1a_ops(res.cigar_ops(i)) if rec["cigar_len"][i] else 2166136261 for i in range(n)], np.uint32)
+    assert (hashes == exp["cigar_hash"]).all()
+    return res
+
+
+def test_gpu_config4_shape_mixed_lengths_and_windows(gpu, oracle_mod, capfd):
+    """BASELINE configs[3] in miniature (1 GPU): read lengths {75,100,125,150,200,250}, windows of 200-600 bp,
+    one window per ~1000 reads, defaults (3,2,3,1): short reads stay in the 8-bit pass, long ones are rescored."""
+    reads, refs, rid = _windows_reads(40, 996, [75, 100, 125, 150, 200, 250], 200, 600)
+    jobs = JobTable.from_sequences(reads, refs, rid, 3, 1, encoded=True)
+    res = _check_all(gpu, oracle_mod, jobs, (3, 2), capfd)
+    assert set(res.records["mode"].tolist()) == {0, 1}
+
+
+def test_gpu_config5_shape_penalty_grid_per_read_windows(gpu, oracle_mod, capfd):
+    """BASELINE configs[4] at the job-list level: per-read 300 bp windows x the gap-penalty grid of
+    varaln.pyx:1127-1143 (retarget / grid_search, pileup.pyx:639-648), CIGAR bit-exact."""
+    reads, refs, rid = _windows_reads(6000, 1, [150], 300, 300)
+    grid = [(3, 1), (3, 0), (5, 1), (5, 0), (4, 1), (4, 0)]
+    R, I, GO, GE = [], [], [], []
+    for r, w in zip(reads, rid):
+        for go, ge in grid:
+            R.append(r); I.append(w); GO.append(go); GE.append(ge)
+    jobs = JobTable.from_sequences(R, refs, I, GO, GE, encoded=True)
+    _check_all(gpu, oracle_mod, jobs, (3, 2), capfd)
