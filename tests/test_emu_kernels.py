@@ -116,3 +116,24 @@ def test_emu_mixed_lengths_many_windows(emu, oracle_mod, port):
     _compare(res, [(reads[i], refs[rid[i]], 3, 1) for i in range(len(reads))], port, mat)
     modes = set(res.records["mode"].tolist())
     assert modes == {0, 1}      # short reads stay in the 8-bit pass, long ones take the 16-bit pass
+
+
+def test_emu_long_reads_generic_kernel(emu, oracle_mod, port):
+    """Reads of 260..500 bp need segLen 33..63: the branch-guarded long-read instantiation."""
+    rng = np.random.default_rng(8)
+    w = rng.integers(0, 4, 700).astype(np.int8)
+    reads = []
+    for L in (260, 333, 400, 500):
+        st = int(rng.integers(0, 150))
+        r = w[st:st + L].copy()
+        m = rng.random(L) < 0.04
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        reads.append(np.concatenate([r[:L // 2], r[L // 2 + 3:], rng.integers(0, 4, 3).astype(np.int8)]))
+    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), [3, 5, 3, 4], [1, 0, 1, 1], encoded=True)
+    for scoring in ((3, 2), (1, 1)):
+        a = emu(0, *scoring)
+        res = a.align(jobs)
+        assert a.status == 0
+        mat = oracle_mod.dna_matrix(*scoring)
+        for i, r in enumerate(reads):
+            assert res.as_dict(i) == port.align(r, w, mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])), (scoring, i)

@@ -144,3 +144,37 @@ def test_gpu_config5_shape_penalty_grid_per_read_windows(gpu, oracle_mod, capfd)
             R.append(r); I.append(w); GO.append(go); GE.append(ge)
     jobs = JobTable.from_sequences(R, refs, I, GO, GE, encoded=True)
     _check_all(gpu, oracle_mod, jobs, (3, 2), capfd)
+
+
+def test_gpu_long_reads_and_long_windows(gpu, oracle_mod, capfd):
+    """Reads up to 512 bp (long-read instantiation, segLen 33..64) and windows up to 4096 bp."""
+    rng = np.random.default_rng(4242)
+    refs = [rng.integers(0, 4, n).astype(np.int8) for n in (700, 1500, 4096)]
+    reads, rid, go, ge = [], [], [], []
+    for i in range(600):
+        k = i % 3
+        w = refs[k]
+        L = int(rng.integers(257, 513))
+        st = int(rng.integers(0, len(w) - 100))
+        r = np.resize(w[st:], L).copy()
+        m = rng.random(L) < (0.0, 0.03, 0.1)[i % 3]
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        if i % 5 == 0:
+            cut = int(rng.integers(20, L - 20))
+            r = np.concatenate([r[:cut], r[cut + int(rng.integers(1, 30)):]])
+        reads.append(r); rid.append(k)
+        g = [(3, 1), (5, 0), (1, 1), (4, 1), (2, 2)][i % 5]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+    for scoring in ((3, 2), (1, 1)):
+        _check_all(gpu, oracle_mod, jobs, scoring, capfd)
+
+
+def test_gpu_limits_are_refused_loudly(gpu):
+    import indelpost_amd as ip
+    too_long_read = JobTable.from_sequences([np.zeros(513, np.int8)], [np.zeros(100, np.int8)], [0], 3, 1, encoded=True)
+    with pytest.raises(ip.IpxError):
+        gpu.align(too_long_read)
+    too_long_ref = JobTable.from_sequences([np.zeros(50, np.int8)], [np.zeros(4097, np.int8)], [0], 3, 1, encoded=True)
+    with pytest.raises(ip.IpxError):
+        gpu.align(too_long_ref)
