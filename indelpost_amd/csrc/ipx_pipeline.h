@@ -145,11 +145,14 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
-            const int rowcap = d.max_read_len > 0 ? d.max_read_len : 1;
+            // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
+            const int want = d.max_read_len > 0 ? d.max_read_len : 1;
+            const int rowcap32 = want < 560 ? want : 560, rowcap64 = want < 272 ? want : 272;
 #define IPX_TBF_LAUNCH(BW)                                                                                        \
-    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(BW, rowcap), b, \
+    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>, ws.tbf_waves, 64,                                   \
+              ipx_tbf_lds_bytes(BW, BW <= 3 ? rowcap32 : rowcap64), b,                                            \
               (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
-              rowcap, ws.tb_esc, ws.tb_esc_n);
+              BW <= 3 ? rowcap32 : rowcap64, ws.tb_esc, ws.tb_esc_n);
             IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)
             IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
 #undef IPX_TBF_LAUNCH
