@@ -676,10 +676,11 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
 // the job's own letters and the CIGAR.  Cells keep the reference's linear index width_d*i + (j-shift),
 // so out-of-band reads alias exactly as in the reference.  Jobs that need a second band iteration
 // (max < score, ssw.c:669), more rows than `rowcap` or more than 32 CIGAR runs go to `next`.
-// Dynamic LDS: 64 B matrix | 32*64 CIGAR ops | rowcap*64 direction words (4 or 8 bytes)
+// Dynamic LDS: 64 B matrix | 32*64 CIGAR ops.   Global: rowcap*64 direction words (4 or 8 bytes) per block
 // ------------------------------------------------------------------------------------------------
 #define IPX_TBF_CIG 32
-static inline int ipx_tbf_lds_bytes(int bw, int rowcap) { return 64 + IPX_TBF_CIG * 256 + rowcap * (bw <= 3 ? 256 : 512); }
+static inline int ipx_tbf_lds_bytes() { return 64 + IPX_TBF_CIG * 256; }
+IPX_HD size_t ipx_tbf_scratch_bytes_per_block(int rowcap) { return (size_t)rowcap * 512; }   // sized for 64-bit words
 template <int BW> struct IpxTbWord { typedef uint32_t type; };
 template <> struct IpxTbWord<4> { typedef uint64_t type; };
 template <> struct IpxTbWord<5> { typedef uint64_t type; };
@@ -688,7 +689,7 @@ template <> struct IpxTbWord<7> { typedef uint64_t type; };
 
 template <int BW>
 IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
-                               uint32_t *next, uint32_t *next_n)
+                               unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n)
 {
     constexpr int WD = 2 * BW + 1, W = 2 * BW + 3;
     typedef typename IpxTbWord<BW>::type word_t;
@@ -696,7 +697,7 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
     unsigned char *lds = IPX_LDS_BASE;
     int8_t *matl = (int8_t *)lds;
     uint32_t *cig = (uint32_t *)(lds + 64) + lane;                      // [k*64]
-    word_t *dirw = (word_t *)(lds + 64 + IPX_TBF_CIG * 256) + lane;     // [row*64]
+    word_t *dirw = (word_t *)(dir_scratch + (size_t)IPX_BID * ipx_tbf_scratch_bytes_per_block(rowcap)) + lane;   // [row*64]
     if (lane < 25) matl[lane] = b.mat[lane];
     IPX_SYNC();
     const uint32_t n = *list_n;
@@ -795,7 +796,11 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
         bool fail = false;
         if (!esc) {
             // ---- trace back (ssw.c:673-751) ----
+            // the walk moves up one row at most per step: keep the words of rows i and i-1 in registers and
+            // fetch row i-2 as soon as the walk moves (a cell index outside those two rows reads memory)
             int i = readLen - 1, j = refLen - 1, plane = 2, prev = 0;   // op: 0 M, 1 I, 2 D
+            int wrow = i;                                               // row held in w0; w1 = row wrow-1
+            word_t w0 = i >= 0 ? dirw[i * 64] : 0, w1 = i >= 1 ? dirw[(i - 1) * 64] : 0;
             while (i >= 0 && j > 0) {
                 const int x = i - BW > 0 ? i - BW : 0;
                 const int cell = WD * i + (j - x);
@@ -803,19 +808,22 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
                 if (cell >= 0) {
                     const int row = cell / WD, slot = cell - row * WD;
                     if (row < readLen) {
-                        const int v = (int)((dirw[row * 64] >> (4 * slot)) & 15u);
+                        const word_t ww = row == wrow ? w0 : row == wrow - 1 ? w1 : dirw[row * 64];
+                        const int v = (int)((ww >> (4 * slot)) & 15u);
                         if (v) {
                             const int de = 2 + ((v - 1) & 1), df = 4 + (((v - 1) >> 1) & 1), dh = (v - 1) >> 2;
                             code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
                         }
                     }
                 }
+                const int iold = i;
                 if (code == 1) { --i; --j; plane = 2; op = 0; }
                 else if (code == 2) { --i; plane = 0; op = 1; }
                 else if (code == 3) { --i; plane = 2; op = 1; }
                 else if (code == 4) { --j; plane = 1; op = 2; }
                 else if (code == 5) { --j; plane = 2; op = 2; }
                 else { fail = true; break; }
+                if (i != iold) { wrow = i; w0 = w1; w1 = i >= 1 ? dirw[(i - 1) * 64] : 0; }
                 if (op == prev) ++e;
                 else {
                     ++lcnt;

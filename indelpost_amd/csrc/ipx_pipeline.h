@@ -17,9 +17,11 @@ struct IpxWorkspace {
     uint32_t *tb_esc, *tb_esc_n;        // jobs the LDS-resident traceback hands to the general kernel
     uint32_t *tb_next, *tb_next_n;      // jobs whose band outgrew the tier-0 scratch
     IpxTbScratch tb0, tb1;
+    unsigned char *tbf_scratch;         // direction words of the fast traceback: ipx_tbf_scratch_bytes_per_block(rowcap) per block
     int tbf_waves, tb0_waves, tb1_waves;
 };
 
+#define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
 
 struct IpxDims {
@@ -147,12 +149,11 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs), 256, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
             const int want = d.max_read_len > 0 ? d.max_read_len : 1;
-            const int rowcap32 = want < 560 ? want : 560, rowcap64 = want < 272 ? want : 272;
+            const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;
 #define IPX_TBF_LAUNCH(BW)                                                                                        \
-    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>, ws.tbf_waves, 64,                                   \
-              ipx_tbf_lds_bytes(BW, BW <= 3 ? rowcap32 : rowcap64), b,                                            \
+    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(), b,            \
               (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
-              BW <= 3 ? rowcap32 : rowcap64, ws.tb_esc, ws.tb_esc_n);
+              rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n);
             IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)
             IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
 #undef IPX_TBF_LAUNCH

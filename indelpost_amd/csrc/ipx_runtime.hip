@@ -65,7 +65,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_next, tb_esc, tb0, tb1, maxcol;
+    DevBuf perm, tb_list, tb_next, tb_esc, tb0, tb1, maxcol, tbf;
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -181,7 +181,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_next, &c->tb_esc, &c->tb0, &c->tb1, &c->maxcol})
+                      &c->tb_list, &c->tb_next, &c->tb_esc, &c->tb0, &c->tb1, &c->maxcol, &c->tbf})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -289,8 +289,14 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
     int wf = (int)((n_jobs + 63) / 64);
     if (wf < 1) wf = 1;
-    if (wf > c->num_cu * 8) wf = c->num_cu * 8;
+    if (wf > c->num_cu * 16) wf = c->num_cu * 16;
     c->ws.tbf_waves = wf;
+    {
+        const int want = d.max_read_len > 0 ? d.max_read_len : 1;
+        const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;
+        if (c->tbf.ensure(ipx_tbf_scratch_bytes_per_block(rowcap) * (size_t)wf + 64)) return IPX_ERR_NO_DEVICE;
+        c->ws.tbf_scratch = c->tbf.as<unsigned char>();
+    }
     int w0 = (int)((n_jobs + 63) / 64);
     if (w0 < 1) w0 = 1;
     if (w0 > c->num_cu * 2) w0 = c->num_cu * 2;          // only what the LDS-resident kernel hands over

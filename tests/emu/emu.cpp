@@ -225,6 +225,8 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
     ws.tb0_waves = 2;
     ws.tbf_waves = 2;
+    ws.tbf_scratch = (unsigned char *)malloc(ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 2 + 64);
+    memset(ws.tbf_scratch, 0x5A, ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 2);
     ws.tb1_waves = 1;
     auto mk = [](const IpxTbSizing &s, int waves) {
         IpxTbScratch t;
@@ -256,6 +258,6 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
     free(ws.tb_list); free(ws.tb_next); free(ws.tb_esc); free(ws.tb_list_n); free(ws.tb_next_n);
     for (IpxTbScratch *t : {&ws.tb0}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
-    free(ws.tb1.dir); free(ws.tb1.cig);
+    free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tbf_scratch);
     return 0;
 }
