@@ -847,170 +847,17 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_traceback: banded affine DP + traceback -> BAM-encoded CIGAR (banded_sw, ssw.c:588-772)
-// One lane per job.  Per-lane scratch (interleaved [slot][lane] so a wave's accesses coalesce):
-//   hb/eb/hc : int32 band rows          (arrcap slots each)
-//   dir      : 1 byte per DP cell       (dircap cells): bit7 written | bits3:2 H source (0 diag,
-//              1 E, 2 F) | bit1 F came from open | bit0 E came from open -- the reference's three
-//              direction planes of a cell, kept at the reference's linear cell index so that
-//              out-of-band reads alias the same cells; never-written cells read 0 = the
-//              reference's "Trace back error" path (it reads uninitialised heap there)
-//   cig      : uint32 ops, reversed     (cigcap)
-// Jobs whose band outgrows the scratch are appended to `next` for a launch with more scratch.
-// ------------------------------------------------------------------------------------------------
+// scratch of the one-wave-per-job kernel: direction bytes and CIGAR runs, one region per block
 struct IpxTbScratch {
-    int32_t *hb, *eb, *hc;
     uint8_t *dir;
     uint32_t *cig;
     int32_t arrcap, dircap, cigcap;
 };
 
-IPX_KERNEL_WAVE void k_traceback(IpxBatch b, const uint32_t *list, const uint32_t *list_n, IpxTbScratch s,
-                            uint32_t *next, uint32_t *next_n)
-{
-    const int lane = lane_id();
-    int8_t *matl = (int8_t *)IPX_LDS_BASE;
-    if (IPX_TID < 25) matl[IPX_TID] = b.mat[IPX_TID];
-    IPX_SYNC();
-    const int waves_per_block = IPX_BDIM / 64;
-    const int64_t wslot = (int64_t)IPX_BID * waves_per_block + IPX_TID / 64;   // scratch slot of this wave
-    int32_t *hb = s.hb + wslot * (int64_t)s.arrcap * 64 + lane;
-    int32_t *eb = s.eb + wslot * (int64_t)s.arrcap * 64 + lane;
-    int32_t *hc = s.hc + wslot * (int64_t)s.arrcap * 64 + lane;
-    uint8_t *dir = s.dir + wslot * (int64_t)s.dircap * 64 + lane;
-    uint32_t *cig = s.cig + wslot * (int64_t)s.cigcap * 64 + lane;
-    const uint32_t n = *list_n;
-    const int64_t nwaves = (int64_t)IPX_GDIM * waves_per_block;
-
-    for (int64_t base = wslot * 64; base < (int64_t)n; base += nwaves * 64) {
-        const int64_t li = base + lane;
-        if (li >= (int64_t)n) continue;
-        const int64_t jb = list[li];
-        IpxResult r = b.res[jb];
-        const int rid = b.ref_id[jb];
-        const int fullRef = b.ref_len[rid];
-        const int8_t *refp = b.refs_packed + b.refp_off[rid];
-        const int8_t *readp = b.reads + b.read_off[jb] + r.read_begin1;
-        const int rb = r.ref_begin1;
-        const int refLen = r.ref_end1 - r.ref_begin1 + 1;             // ssw.c:897-899
-        const int readLen = r.read_end1 - r.read_begin1 + 1;
-        const int gapO = b.gap_open[jb], gapE = b.gap_ext[jb];
-        const int score = r.score1;
-        int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-        const int len = refLen > readLen ? refLen : readLen;
-        int mx = 0, width = 0, width_d = 0, cap = 0, extent = 0;
-        bool escalate = false;
-
-        do {
-            width = bw * 2 + 3;
-            width_d = bw * 2 + 1;
-            const int64_t cells = (int64_t)width_d * (readLen > 0 ? readLen : 1);
-            if (width + 1 > s.arrcap || cells > (int64_t)s.dircap) { escalate = true; break; }
-            for (int q = cap; q < width + 1; ++q) { hb[q * 64] = 0; eb[q * 64] = 0; hc[q * 64] = 0; }
-            if (width + 1 > cap) cap = width + 1;
-            for (int q = extent; q < (int)cells; ++q) dir[(int64_t)q * 64] = 0;
-            if ((int)cells > extent) extent = (int)cells;
-            for (int j = 1; j < width - 1; ++j) hb[j * 64] = 0;                          // ssw.c:627
-            for (int i = 0; i < readLen; ++i) {
-                int beg = 0, end = refLen - 1, u = 0;
-                if (i - bw > beg) beg = i - bw;
-                if (i + bw < end) end = i + bw;
-                const int edge = end + 1 < width - 1 ? end + 1 : width - 1;                // ssw.c:632
-                int f = 0;
-                hb[0] = 0; eb[0] = 0; hb[edge * 64] = 0; eb[edge * 64] = 0; hc[0] = 0;     // ssw.c:633
-                const int x = i - bw > 0 ? i - bw : 0;                                   // band shift of row i
-                const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;                          // ... of row i-1
-                int rc = readp[i];
-                if ((unsigned)rc > 4u) rc = 4;
-                int hleft = 0;                                                             // h_c[b]: cell to the left
-                for (int j = beg; j <= end; ++j) {
-                    u = j - x + 1;                                                         // set_u (ssw.c:92)
-                    const int e = j - xp + 1;
-                    const int d = j - 1 - xp + 1;
-                    int t1 = i == 0 ? -gapO : hb[e * 64] - gapO;                           // ssw.c:644-648
-                    int t2 = i == 0 ? -gapE : eb[e * 64] - gapE;
-                    const int ev = t1 > t2 ? t1 : t2;
-                    const int de = t1 > t2 ? 1 : 0;
-                    eb[u * 64] = ev;
-                    t1 = hleft - gapO;                                                     // ssw.c:650-653 (h_c[0] = 0 at the band's left edge)
-                    t2 = f - gapE;
-                    f = t1 > t2 ? t1 : t2;
-                    const int df = t1 > t2 ? 1 : 0;
-                    const int e1 = ev > 0 ? ev : 0;                                        // ssw.c:655-664
-                    const int f1 = f > 0 ? f : 0;
-                    t1 = e1 > f1 ? e1 : f1;
-                    const int ri = rb + j;
-                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
-                    t2 = hb[d * 64] + matl[rcode * 5 + rc];
-                    const int hv = t1 > t2 ? t1 : t2;
-                    hc[u * 64] = hv;
-                    hleft = hv;
-                    if (hv > mx) mx = hv;
-                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
-                    dir[((int64_t)width_d * i + (j - x)) * 64] = (uint8_t)(0x80 | (dh << 2) | (df << 1) | de);
-                }
-                for (int j = 1; j <= u; ++j) hb[j * 64] = hc[j * 64];                       // ssw.c:666
-            }
-            bw *= 2;
-        } while (mx < score && bw <= len);                                                // ssw.c:669
-        if (escalate) {
-            if (next) next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb;
-            else atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH);
-            continue;
-        }
-        bw /= 2;
-
-        // ---- trace back (ssw.c:673-751) ----
-        int i = readLen - 1, j = refLen - 1, e = 0, lcnt = 0, plane = 2;
-        int op = 0, prev = 0;                                   // 0 M, 1 I, 2 D
-        bool fail = false, full = false;
-        while (i >= 0 && j > 0) {
-            const int x = i - bw > 0 ? i - bw : 0;
-            const int64_t cell = (int64_t)width_d * i + (j - x);
-            int code = 0;
-            if (cell >= 0 && cell < extent) {
-                const int v = dir[cell * 64];
-                if (v & 0x80) {
-                    const int de = 2 + (v & 1), df = 4 + ((v >> 1) & 1), dh = (v >> 2) & 3;
-                    code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
-                }
-            }
-            if (code == 1) { --i; --j; plane = 2; op = 0; }
-            else if (code == 2) { --i; plane = 0; op = 1; }
-            else if (code == 3) { --i; plane = 2; op = 1; }
-            else if (code == 4) { --j; plane = 1; op = 2; }
-            else if (code == 5) { --j; plane = 2; op = 2; }
-            else { fail = true; break; }
-            if (op == prev) ++e;
-            else {
-                ++lcnt;
-                if (lcnt + 2 > s.cigcap) { full = true; break; }
-                cig[(lcnt - 1) * 64] = ((uint32_t)e << 4) | (uint32_t)prev;
-                prev = op;
-                e = 1;
-            }
-        }
-        if (full) {
-            if (next) next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb;
-            else atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH);
-            continue;
-        }
-        if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; continue; }                // ssw.c:911
-        if (op == 0) { ++lcnt; cig[(lcnt - 1) * 64] = ((uint32_t)(e + 1) << 4); }          // ssw.c:734-751
-        else { lcnt += 2; cig[(lcnt - 2) * 64] = ((uint32_t)e << 4) | (uint32_t)op; cig[(lcnt - 1) * 64] = (1u << 4); }
-        const uint32_t off = atomic_add_u32(b.cigar_cursor, (uint32_t)lcnt);
-        if (off + (uint32_t)lcnt > b.cigar_cap) { atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL); continue; }
-        for (int k = 0; k < lcnt; ++k) b.cigar_pool[off + k] = cig[(lcnt - 1 - k) * 64];   // reverse (ssw.c:754-762)
-        r.cigar_off = off;
-        r.cigar_len = (uint16_t)lcnt;
-        b.res[jb] = r;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_tb_coop: banded_sw (ssw.c:588-772) for the few jobs whose band keeps doubling (large indels, or a
-// forward score the banded DP never reaches, so the band grows to the full rectangle).  ONE WAVEFRONT
+// k_tb_coop: banded_sw (ssw.c:588-772), general form, for the jobs k_tb_fast hands over: first band > 7,
+// band doubling (max < score, ssw.c:669: large indels, or a forward score the banded DP never reaches, so
+// the band grows to the full rectangle), very long reads or CIGARs.  ONE WAVEFRONT
 // PER JOB: the cells of a DP row are spread over the 64 lanes (one contiguous chunk per lane).  The only
 // dependency inside a row is the horizontal-gap chain f_j = max(H_{j-1} - gapO, f_{j-1} - gapE); with
 // A_j = max(E_j, 0, diag_j) ("H without F") it is the max-plus recurrence
@@ -1018,8 +865,12 @@ IPX_KERNEL_WAVE void k_traceback(IpxBatch b, const uint32_t *list, const uint32_
 // a prefix scan: each lane folds its chunk, the lane aggregates are scanned across the wave, and a
 // second sweep produces H, the direction planes (with the reference's tie-breaks, which need the actual
 // H_{j-1} and f_{j-1}; across a lane boundary they are handed over through LDS) and the new band row.
-// Band rows live in LDS, direction bytes (same encoding and linear cell index as k_traceback) in a
-// per-block global scratch; the trace back itself is sequential (lane 0).
+// Band rows live in LDS; direction bytes -- 1 byte per DP cell: bit7 written | bits3:2 H source (0 diag,
+// 1 E, 2 F) | bit1 F came from open | bit0 E came from open, i.e. the reference's three direction planes
+// of a cell, kept at the reference's linear cell index so that out-of-band reads and cells left over from
+// an earlier, narrower band iteration alias exactly as in the reference; never-written cells read 0 = the
+// reference's "Trace back error" path (it reads uninitialised heap there) -- sit in a per-block global
+// scratch; the trace back itself is sequential (lane 0).
 // Dynamic LDS: 64 B matrix | 128 ints hand-over | 4 * arrcap ints (h_b, e_b, h_c, new e_b)
 // ------------------------------------------------------------------------------------------------
 static inline int ipx_tbc_lds_bytes(int arrcap) { return 64 + 512 + 16 * arrcap; }
@@ -1102,18 +953,37 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
                     agg = (agg - g > a - gapO) ? agg - g : a - gapO;                       // F carried out after this cell
                 }
                 int dec = (c1 - c0) * g;
-                for (int sft = 1; sft < 64; sft <<= 1) {                                   // inclusive scan over lanes
-                    const int src = lane >= sft ? lane - sft : lane;
-                    const int pd = (int)xl_shfl((uint32_t)dec, src);
-                    const int pa = (int)xl_shfl((uint32_t)agg, src);
-                    if (lane >= sft) {
-                        const int cand = pa - dec;                                         // earlier block, then this one
-                        agg = cand > agg ? cand : agg;
-                        dec = dec + pd > (1 << 28) ? (1 << 28) : dec + pd;
-                    }
+                // inclusive scan of (dec, agg) over the lanes: DPP row shifts inside each 16-lane row, then the
+                // three row totals (v_readlane) are folded into the rows behind them
+                const int CAPD = 1 << 28;
+#define IPX_SCAN_STEP(N)                                                                      \
+                {                                                                             \
+                    const int pd_ = (int)xl_row_shr<N>((uint32_t)dec), pa_ = (int)xl_row_shr<N>((uint32_t)agg); \
+                    if ((lane & 15) >= N) {                                                   \
+                        const int cand_ = pa_ - dec;                                          \
+                        agg = cand_ > agg ? cand_ : agg;                                      \
+                        dec = dec + pd_ > CAPD ? CAPD : dec + pd_;                            \
+                    }                                                                         \
                 }
-                const int pdx = (int)xl_shfl((uint32_t)dec, lane > 0 ? lane - 1 : 0);
-                const int pax = (int)xl_shfl((uint32_t)agg, lane > 0 ? lane - 1 : 0);
+                IPX_SCAN_STEP(1) IPX_SCAN_STEP(2) IPX_SCAN_STEP(4) IPX_SCAN_STEP(8)
+#undef IPX_SCAN_STEP
+                const int d0 = (int)xl_readlane<15>((uint32_t)dec), a0r = (int)xl_readlane<15>((uint32_t)agg);
+                const int d1 = (int)xl_readlane<31>((uint32_t)dec), a1r = (int)xl_readlane<31>((uint32_t)agg);
+                const int d2 = (int)xl_readlane<47>((uint32_t)dec), a2r = (int)xl_readlane<47>((uint32_t)agg);
+                // prefix (everything before row q): P1 = T0, P2 = T0 then T1, P3 = P2 then T2
+                const int p1d = d0, p1a = a0r;
+                const int p2d = d0 + d1 > CAPD ? CAPD : d0 + d1, p2a = (a0r - d1 > a1r) ? a0r - d1 : a1r;
+                const int p3d = p2d + d2 > CAPD ? CAPD : p2d + d2, p3a = (p2a - d2 > a2r) ? p2a - d2 : a2r;
+                const int rowq = lane >> 4;
+                const int ppd = rowq == 1 ? p1d : rowq == 2 ? p2d : p3d, ppa = rowq == 1 ? p1a : rowq == 2 ? p2a : p3a;
+                // exclusive value for this lane = inclusive value of lane-1 (row-local, before the prefix is folded in)
+                int pdx = (int)xl_row_shr<1>((uint32_t)dec), pax = (int)xl_row_shr<1>((uint32_t)agg);
+                if ((lane & 15) == 0) { pdx = 0; pax = NEG; }                              // nothing inside the row before lane 16q
+                if (rowq > 0) {                                                            // prefix first, then the row-local part
+                    const int cand = ppa - pdx;
+                    pax = cand > pax ? cand : pax;
+                    pdx = pdx + ppd > CAPD ? CAPD : pdx + ppd;
+                }
                 // h_c[0] = 0 and f = 0 before the row's first cell -> the F entering cell 0 is max(-gapO, -gapE) = -g
                 int fcur = -g;
                 if (lane > 0) { const int a0 = -g - pdx; fcur = a0 > pax ? a0 : pax; }

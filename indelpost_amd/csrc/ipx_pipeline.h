@@ -14,11 +14,10 @@
 struct IpxWorkspace {
     IpxPlan plan;
     uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: 7 lists (first band 1..7) of n_jobs slots; 8 counters, the 8th = tb_esc_n
-    uint32_t *tb_esc, *tb_esc_n;        // jobs the LDS-resident traceback hands to the general kernel
-    uint32_t *tb_next, *tb_next_n;      // jobs whose band outgrew the tier-0 scratch
-    IpxTbScratch tb0, tb1;
+    uint32_t *tb_esc, *tb_esc_n;        // jobs the fast traceback hands to the general (one wave per job) kernel
+    IpxTbScratch tb1;
     unsigned char *tbf_scratch;         // direction words of the fast traceback: ipx_tbf_scratch_bytes_per_block(rowcap) per block
-    int tbf_waves, tb0_waves, tb1_waves;
+    int tbf_waves, tb1_waves;
 };
 
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
@@ -113,7 +112,6 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(b.cigar_cursor, 1);
     be.zero_u32(ws.tb_list_n, 8);
-    be.zero_u32(ws.tb_next_n, 1);
 
     if (b.score_size == 2 && b.word_first_len > 0 && d.max_read_len >= b.word_first_len) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
@@ -157,11 +155,9 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)
             IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
 #undef IPX_TBF_LAUNCH
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 0), k_traceback, ws.tb0_waves, 64, 64, b, (const uint32_t *)ws.tb_esc,
-                      (const uint32_t *)ws.tb_esc_n, ws.tb0, ws.tb_next, ws.tb_next_n);
-            // what still does not fit (wide bands): one wavefront per job
+            // everything else: one wavefront per job
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_tb_coop, ws.tb1_waves, 64, ipx_tbc_lds_bytes(ws.tb1.arrcap), b,
-                      (const uint32_t *)ws.tb_next, (const uint32_t *)ws.tb_next_n, ws.tb1.dir, (int64_t)ws.tb1.dircap,
+                      (const uint32_t *)ws.tb_esc, (const uint32_t *)ws.tb_esc_n, ws.tb1.dir, (int64_t)ws.tb1.dircap,
                       ws.tb1.arrcap, ws.tb1.cig, ws.tb1.cigcap);
         }
     }
@@ -182,14 +178,6 @@ static inline int ipx_word_first_len(const int8_t *mat, int bias)
 
 // scratch sizing shared by both back-ends -------------------------------------------------------
 struct IpxTbSizing { int arrcap, dircap, cigcap; };
-static inline IpxTbSizing ipx_tb0_sizing(const IpxDims &d)
-{
-    IpxTbSizing s;
-    s.arrcap = 2 * 8 + 4;                                        // band_width <= 8
-    s.dircap = (2 * 8 + 1) * (d.max_read_len > 0 ? d.max_read_len : 1);
-    s.cigcap = 64;
-    return s;
-}
 static inline IpxTbSizing ipx_tb1_sizing(const IpxDims &d)
 {
     IpxTbSizing s;
@@ -198,10 +186,6 @@ static inline IpxTbSizing ipx_tb1_sizing(const IpxDims &d)
     s.dircap = (2 * (len > 0 ? len : 1) + 1) * (d.max_read_len > 0 ? d.max_read_len : 1);
     s.cigcap = d.max_read_len + d.max_ref_len + 8;
     return s;
-}
-static inline size_t ipx_tb_bytes_per_wave(const IpxTbSizing &s)
-{
-    return 64ull * (3ull * 4ull * (size_t)s.arrcap + (size_t)s.dircap + 4ull * (size_t)s.cigcap);
 }
 // the one-wave-per-job kernel needs direction bytes and CIGAR runs for ONE job per block
 static inline size_t ipx_tbc_bytes_per_block(const IpxTbSizing &s)

@@ -65,7 +65,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_next, tb_esc, tb0, tb1, maxcol, tbf;
+    DevBuf perm, tb_list, tb_esc, tb1, maxcol, tbf;
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -181,7 +181,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_next, &c->tb_esc, &c->tb0, &c->tb1, &c->maxcol, &c->tbf})
+                      &c->tb_list, &c->tb_esc, &c->tb1, &c->maxcol, &c->tbf})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -199,21 +199,6 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
     c->bias = -bias;
     c->flag = flag & 255; c->filters = filters & 0xFFFF; c->filterd = filterd; c->score_size = score_size;
     return IPX_OK;
-}
-
-static int carve_tb(ipx_ctx *c, DevBuf &buf, const IpxTbSizing &s, int waves, IpxTbScratch *out)
-{
-    const size_t per = ipx_tb_bytes_per_wave(s);
-    if (buf.ensure(per * (size_t)waves)) return IPX_ERR_NO_DEVICE;
-    char *p = buf.as<char>();
-    const size_t arr = 64ull * 4ull * (size_t)s.arrcap * (size_t)waves;
-    out->hb = (int32_t *)p; p += arr;
-    out->eb = (int32_t *)p; p += arr;
-    out->hc = (int32_t *)p; p += arr;
-    out->cig = (uint32_t *)p; p += 64ull * 4ull * (size_t)s.cigcap * (size_t)waves;
-    out->dir = (uint8_t *)p;
-    out->arrcap = s.arrcap; out->dircap = s.dircap; out->cigcap = s.cigcap;
-    return 0;
 }
 
 int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const int8_t *refs,
@@ -255,7 +240,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
         c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
-        c->tb_next.ensure(4 * (size_t)n_jobs + 4) || c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
+        c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
     if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
@@ -285,8 +270,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->profiling = prof;
     if (be.err != hipSuccess) { set_err("k_pack_refs launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }
 
-    // traceback scratch: tier 0 (band <= 8) for every resident wave, tier 1 (any band) for a few
-    const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
+    // traceback scratch: direction words of the fast kernels, direction bytes + CIGAR runs of the general kernel
+    const IpxTbSizing s1 = ipx_tb1_sizing(d);
     int wf = (int)((n_jobs + 63) / 64);
     if (wf < 1) wf = 1;
     if (wf > c->num_cu * 16) wf = c->num_cu * 16;
@@ -297,16 +282,10 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         if (c->tbf.ensure(ipx_tbf_scratch_bytes_per_block(rowcap) * (size_t)wf + 64)) return IPX_ERR_NO_DEVICE;
         c->ws.tbf_scratch = c->tbf.as<unsigned char>();
     }
-    int w0 = (int)((n_jobs + 63) / 64);
-    if (w0 < 1) w0 = 1;
-    if (w0 > c->num_cu * 2) w0 = c->num_cu * 2;          // only what the LDS-resident kernel hands over
-    const size_t lim0 = 512ull << 20;
-    while (w0 > 1 && ipx_tb_bytes_per_wave(s0) * (size_t)w0 > lim0) w0 /= 2;
     int w1 = c->num_cu * 8;                                  // one job per block in k_tb_coop (latency-bound: many blocks)
     const size_t lim1 = 1024ull << 20;
     while (w1 > 1 && ipx_tbc_bytes_per_block(s1) * (size_t)w1 > lim1) w1 /= 2;
-    c->ws.tb0_waves = w0; c->ws.tb1_waves = w1;
-    if (carve_tb(c, c->tb0, s0, w0, &c->ws.tb0)) return IPX_ERR_NO_DEVICE;
+    c->ws.tb1_waves = w1;
     if (c->tb1.ensure(ipx_tbc_bytes_per_block(s1) * (size_t)w1)) return IPX_ERR_NO_DEVICE;
     memset(&c->ws.tb1, 0, sizeof c->ws.tb1);
     c->ws.tb1.arrcap = s1.arrcap; c->ws.tb1.dircap = (int32_t)(((size_t)s1.dircap + 15) & ~(size_t)15); c->ws.tb1.cigcap = s1.cigcap;
@@ -325,11 +304,9 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.plan.max_cols = nullptr;
     c->ws.plan.perm = c->perm.as<uint32_t>();
     c->ws.tb_list = c->tb_list.as<uint32_t>();
-    c->ws.tb_next = c->tb_next.as<uint32_t>();
     c->ws.tb_esc = c->tb_esc.as<uint32_t>();
     c->ws.tb_list_n = sm; sm += 8;
     c->ws.tb_esc_n = c->ws.tb_list_n + 7;
-    c->ws.tb_next_n = sm; sm += 4;
     uint32_t *cursor = sm; sm += 4;
     uint32_t *status = sm; sm += 4;
 
@@ -464,13 +441,13 @@ int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches)
 float ipx_last_run_ms(ipx_ctx *c) { return c ? c->last_run_ms : 0.f; }
 
 // diagnostic: traceback routing of the last run -- out[0..6] jobs per first band width 1..7, out[7] jobs
-// handed to the general kernel, out[8] jobs handed on to the one-wave-per-job kernel
+// handed to the general (one wave per job) kernel, out[8] unused
 int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out)
 {
     if (!c || !out || !c->ws.tb_list_n) return IPX_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(out, c->ws.tb_list_n, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out + 8, c->ws.tb_next_n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out[8] = 0;
     return IPX_OK;
 }
 

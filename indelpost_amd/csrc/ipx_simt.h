@@ -39,6 +39,7 @@ IPX_DEV uint32_t xl_shfl(uint32_t v, int src) { return ipx_emu::exchange(v, (IPX
 IPX_DEV uint64_t xl_ballot(bool p) { return ipx_emu::ballot(p); }
 IPX_DEV bool xl_any(bool p) { return ipx_emu::ballot(p) != 0; }
 IPX_DEV uint32_t xl_first(uint32_t v) { return ipx_emu::exchange(v, (IPX_TID & ~63)); }
+template <int LANE> IPX_DEV uint32_t xl_readlane(uint32_t v) { return ipx_emu::exchange(v, (IPX_TID & ~63) + LANE); }
 IPX_DEV int lane_id() { return IPX_TID & 63; }
 // lane i <- lane i-1 inside its 16-lane row, first lane of the row <- 0   (DPP row_shr:1)
 IPX_DEV uint32_t xl_row_shr1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) ? (IPX_TID - 1) : -1); }
@@ -101,6 +102,7 @@ IPX_DEV uint32_t xl_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, 
 IPX_DEV uint64_t xl_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 IPX_DEV bool xl_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 IPX_DEV uint32_t xl_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <int LANE> IPX_DEV uint32_t xl_readlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, LANE); }   // v_readlane_b32
 // DPP controls: row_shr:1 = 0x111, quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E,
 // row_mirror = 0x140, row_half_mirror = 0x141.  bound_ctrl=1 -> out-of-row source reads 0.
 IPX_DEV uint32_t xl_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }

@@ -216,33 +216,14 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.plan.perm = zalloc<uint32_t>((size_t)n_jobs);
     ws.plan.max_cols = nullptr;
     ws.tb_list = zalloc<uint32_t>(7 * (size_t)n_jobs);
-    ws.tb_next = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc_n = nullptr;
     ws.tb_list_n = zalloc<uint32_t>(8);
-    ws.tb_next_n = zalloc<uint32_t>(1);
     ws.tb_esc_n = ws.tb_list_n + 7;
-    const IpxTbSizing s0 = ipx_tb0_sizing(d), s1 = ipx_tb1_sizing(d);
-    ws.tb0_waves = 2;
+    const IpxTbSizing s1 = ipx_tb1_sizing(d);
     ws.tbf_waves = 2;
     ws.tbf_scratch = (unsigned char *)malloc(ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 2 + 64);
     memset(ws.tbf_scratch, 0x5A, ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 2);
-    ws.tb1_waves = 1;
-    auto mk = [](const IpxTbSizing &s, int waves) {
-        IpxTbScratch t;
-        t.arrcap = s.arrcap; t.dircap = s.dircap; t.cigcap = s.cigcap;
-        t.hb = (int32_t *)malloc(sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
-        t.eb = (int32_t *)malloc(sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
-        t.hc = (int32_t *)malloc(sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
-        t.dir = (uint8_t *)malloc(64 * (size_t)s.dircap * waves);
-        t.cig = (uint32_t *)malloc(sizeof(uint32_t) * 64 * (size_t)s.cigcap * waves);
-        memset(t.hb, 0x5A, sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);   // scratch starts dirty
-        memset(t.eb, 0x5A, sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
-        memset(t.hc, 0x5A, sizeof(int32_t) * 64 * (size_t)s.arrcap * waves);
-        memset(t.dir, 0x5A, 64 * (size_t)s.dircap * waves);
-        return t;
-    };
-    ws.tb0 = mk(s0, ws.tb0_waves);
     ws.tb1_waves = 2;
     memset(&ws.tb1, 0, sizeof ws.tb1);
     ws.tb1.arrcap = s1.arrcap; ws.tb1.dircap = s1.dircap; ws.tb1.cigcap = s1.cigcap;
@@ -256,8 +237,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     free(packed);
     free(b.maxcol_scratch);
     free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
-    free(ws.tb_list); free(ws.tb_next); free(ws.tb_esc); free(ws.tb_list_n); free(ws.tb_next_n);
-    for (IpxTbScratch *t : {&ws.tb0}) { free(t->hb); free(t->eb); free(t->hc); free(t->dir); free(t->cig); }
+    free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n);
     free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tbf_scratch);
     return 0;
 }
