@@ -17,6 +17,7 @@ typedef uint32_t pk16; // two 16-bit DP cells: lo half = even alignment slot, hi
 #include <string.h>
 #define IPX_KERNEL
 #define IPX_KERNEL_WAVE
+#define IPX_KERNEL_WAVE_OCC(w)
 #define IPX_DEV static inline
 #define IPX_HD static inline
 #define IPX_UNROLL
@@ -82,6 +83,7 @@ IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 #include <hip/hip_runtime.h>
 #define IPX_KERNEL __global__
 #define IPX_KERNEL_WAVE __global__ __launch_bounds__(64)   // block = one wavefront: the whole VGPR file is available
+#define IPX_KERNEL_WAVE_OCC(w) __global__ __launch_bounds__(64, w)   // ... but ask for w waves per SIMD (register budget 512/w)
 #define IPX_DEV __device__ __forceinline__
 #define IPX_HD __host__ __device__ inline
 #define IPX_UNROLL _Pragma("unroll")
