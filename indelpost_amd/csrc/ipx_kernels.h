@@ -244,7 +244,7 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          bound of the exact pass, so "overflow" is certain; reads that neither overflowed nor lost
 //          a carry are exact; the rest are re-run by the exact instantiation (IPX_MODE_NEED_BYTE_EXACT).
 template <int W, int SMAX, bool REV, bool EXACT, bool LOW>
-IPX_KERNEL_WAVE_OCC((SMAX <= 20 ? 4 : SMAX <= 32 ? 2 : 1)) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass)
+IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;

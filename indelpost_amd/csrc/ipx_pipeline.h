@@ -149,7 +149,8 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             const int want = d.max_read_len > 0 ? d.max_read_len : 1;
             const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;
 #define IPX_TBF_LAUNCH(BW)                                                                                        \
-    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>, ws.tbf_waves, 64, ipx_tbf_lds_bytes(), b,            \
+    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW>,                                                    \
+              BW <= 3 ? ws.tbf_waves : (ws.tbf_waves + 7) / 8, 64, ipx_tbf_lds_bytes(), b,   /* wide first bands are rare */ \
               (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
               rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n);
             IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)

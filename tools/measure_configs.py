@@ -1,5 +1,5 @@
 import sys, os, time, numpy as np
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import indelpost_amd as ip
 from indelpost_amd import synth, _lib
 from indelpost_amd.batch import JobTable
