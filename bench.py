@@ -86,6 +86,8 @@ def main():
     n_gpus = args.gpus
     # one process per GPU under torchrun; a plain `python bench.py --gpus N` drives N GPUs from threads
     my_devices = [local_rank] if world > 1 else list(range(n_gpus))
+    if os.environ.get("IPX_BENCH_FORCE_DEVICE"):           # rehearsal of the N>1 path on a one-GPU box
+        my_devices = [int(os.environ["IPX_BENCH_FORCE_DEVICE"])] * len(my_devices)
     n = args.reads_per_gpu
     aligners, tables = [], []
     for k, dev in enumerate(my_devices):
