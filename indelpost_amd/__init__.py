@@ -6,7 +6,7 @@ reference exports from ``indelpost/__init__.py`` that lie outside that path (``V
 """
 from .sswpy import SSW, Alignment, force_align, format_force_align          # noqa: F401
 from .localn import make_aligner, align, align_pileup, realign_pileup_jobs  # noqa: F401
-from .batch import (GpuAligner, JobTable, BatchResult, IpxError, align_sharded, device_count,  # noqa: F401
+from .batch import (GpuAligner, MultiStreamAligner, JobTable, BatchResult, IpxError, align_sharded, device_count,  # noqa: F401
                     dna_score_matrix, encode_dna, cigar_to_string)
 
 __version__ = "0.1.0"

@@ -65,5 +65,27 @@ class EmuAligner:
         used = int((rec["cigar_off"].astype(np.int64) + rec["cigar_len"]).max()) if n else 0
         return BatchResult(rec, pool[:used])
 
+    # staged interface of GpuAligner (the emulator runs at sync time)
+    def upload(self, jobs):
+        self._jobs = jobs
+
+    def run(self):
+        self._res = None
+
+    def sync(self):
+        self._res = self.align(self._jobs)
+
+    def download(self, cigar_ops_per_job=16):
+        return self._res
+
+    def set_profiling(self, on):
+        pass
+
+    def kernel_times(self):
+        return {}
+
+    def last_run_ms(self):
+        return 0.0
+
     def close(self):
         pass

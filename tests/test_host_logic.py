@@ -90,6 +90,19 @@ def test_align_sharded_threads(emu):
     assert all(merged.as_dict(i) == whole.as_dict(i) for i in range(len(reads)))
 
 
+def test_multi_stream_aligner_matches_single(emu):
+    rng = np.random.default_rng(4)
+    refs = [rng.integers(0, 4, 150).astype(np.int8) for _ in range(2)]
+    reads = [np.resize(refs[i % 2][i:], 40 + (i % 30)).copy() for i in range(200)]
+    jobs = JobTable.from_sequences(reads, refs, [i % 2 for i in range(200)], 3, 1, encoded=True)
+    whole = emu(0, 3, 2).align(jobs)
+    ms = ip.MultiStreamAligner(0, 3, 2, streams=3, aligner_cls=emu)
+    got = ms.align(jobs)
+    assert all(got.as_dict(i) == whole.as_dict(i) for i in range(200))
+    small = JobTable.from_sequences(reads[:5], refs, [0] * 5, 3, 1, encoded=True)
+    assert len(ms.align(small)) == 5          # too small to split: one stream
+
+
 def test_out_of_scope_shells_say_so():
     for name in ("Variant", "VariantAlignment", "Contig"):
         with pytest.raises(NotImplementedError):
