@@ -9,7 +9,7 @@ from typing import NamedTuple, Optional, Union
 
 import numpy as np
 
-from .batch import GpuAligner, JobTable, cigar_to_string, dna_score_matrix, encode_dna
+from .batch import MultiStreamAligner, JobTable, cigar_to_string, dna_score_matrix, encode_dna
 
 Alignment = NamedTuple("Alignment", [          # sswpy.pyx:85-94
     ("CIGAR", Optional[str]),
@@ -27,10 +27,11 @@ _shared_gpu = {}
 
 
 def _gpu(device=0):
-    """One GpuAligner per device, shared by every SSW object (created on first use)."""
+    """One multi-stream aligner per device, shared by every SSW object (created on first use).
+    Small batches (a single SSW.align) use one stream; large ones are cut into 4 concurrent slices."""
     g = _shared_gpu.get(device)
     if g is None:
-        g = GpuAligner(device)
+        g = MultiStreamAligner(device, streams=4)
         _shared_gpu[device] = g
     return g
 
