@@ -140,7 +140,7 @@ def main():
         per_step = {k: v[0] / args.steps for k, v in kt.items() if v[1] > 0}
         dom = max((k for k in per_step if k.startswith("dp_") or k.startswith("traceback")), key=lambda k: per_step[k])
         dom_ms = kt[dom][0] / kt[dom][1]                      # average duration of one launch
-        per_launch = n / max(1, min(args.streams, n // 64))   # alignments one launch of the dominant kernel processes
+        per_launch = n / max(1, min(args.streams, n // 50000))   # alignments one launch of the dominant kernel processes
         alg_bytes = (ALG_BYTES_FIXED + 4.0 * mean_cigar) * per_launch + WINDOW_LEN
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes

@@ -266,6 +266,7 @@ class MultiStreamAligner:
         self.device = device
         cls = GpuAligner if aligner_cls is None else aligner_cls
         self.parts = [cls(device, match_score, mismatch_penalty, matrix) for _ in range(max(1, streams))]
+        self.min_jobs_per_stream = 50000
         self._active = self.parts
 
     def close(self):
@@ -278,7 +279,7 @@ class MultiStreamAligner:
         self.matrix = self.parts[0].matrix
 
     def upload(self, jobs):
-        k = len(self.parts) if jobs.n_jobs >= 64 * len(self.parts) else 1
+        k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
         b = shard_bounds(jobs.n_jobs, k)
         self._active = self.parts[:k]
         self._slices = [jobs.shard(b[i], b[i + 1]) for i in range(k)]

@@ -97,6 +97,7 @@ def test_multi_stream_aligner_matches_single(emu):
     jobs = JobTable.from_sequences(reads, refs, [i % 2 for i in range(200)], 3, 1, encoded=True)
     whole = emu(0, 3, 2).align(jobs)
     ms = ip.MultiStreamAligner(0, 3, 2, streams=3, aligner_cls=emu)
+    ms.min_jobs_per_stream = 50
     got = ms.align(jobs)
     assert all(got.as_dict(i) == whole.as_dict(i) for i in range(200))
     small = JobTable.from_sequences(reads[:5], refs, [0] * 5, 3, 1, encoded=True)
