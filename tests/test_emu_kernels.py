@@ -137,3 +137,17 @@ def test_emu_long_reads_generic_kernel(emu, oracle_mod, port):
         mat = oracle_mod.dna_matrix(*scoring)
         for i, r in enumerate(reads):
             assert res.as_dict(i) == port.align(r, w, mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])), (scoring, i)
+
+
+def test_emu_explicit_mask_len(emu, oracle_mod, port):
+    rng = np.random.default_rng(12)
+    w = rng.integers(0, 4, 260).astype(np.int8)
+    w[130:260] = w[0:130]
+    reads = [w[20:100].copy() for _ in range(4)]
+    masks = [15, 40, 5, 14]
+    jobs = JobTable.from_sequences(reads, [w], [0] * 4, 3, 1, encoded=True)
+    jobs.mask_len = np.asarray(masks, np.int32)
+    res = emu(0, 2, 2).align(jobs)
+    mat = oracle_mod.dna_matrix(2, 2)
+    for i in range(4):
+        assert res.as_dict(i) == port.align(reads[i], w, mat, 3, 1, mask_len=masks[i]), i
