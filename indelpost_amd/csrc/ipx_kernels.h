@@ -244,7 +244,7 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          bound of the exact pass, so "overflow" is certain; reads that neither overflowed nor lost
 //          a carry are exact; the rest are re-run by the exact instantiation (IPX_MODE_NEED_BYTE_EXACT).
 template <int W, int SMAX, bool REV, bool EXACT, bool LOW>
-IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass)
+IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
@@ -265,6 +265,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         // ---- locate the tile: class (= segLen), first slot in perm, number of reads -------------
         int cls = cls_lo;
         while (tile >= p.tile_off[cls + 1]) ++cls;
+        if (!EXACT && cls < 64 && ((skip_classes >> cls) & 1ull)) continue;   // class owned by an exact-segLen launch
         const int S = EXACT ? SMAX : (int)xl_first((uint32_t)cls);
         const uint32_t first = p.cls_off[cls] + (tile - p.tile_off[cls]) * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;

@@ -64,7 +64,7 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
         be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW>, be.dp_grid(), 64,                          \
-                  ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass);                                \
+                  ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);                                \
         break;
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
@@ -77,22 +77,27 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 #undef IPX_DP_CASE
 }
 
-// forward passes launch exactly the segLen classes that occur among the reads (known on the host);
-// reverse passes align a read PREFIX, so every class up to the longest read may occur
+// Forward passes launch exactly the segLen classes that occur among the reads (known on the host).
+// Reverse passes align a read PREFIX whose length is only known on the device: almost always the
+// prefix has the read's own class or the one below, so those get their exact-segLen launch and ONE
+// branch-guarded launch sweeps up every other class (it skips the tiles the exact launches own).
 template <class BE, int W, bool REV, bool LOW>
 static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass)
 {
     int top = -1;
     for (int c = 0; c < IPX_NUM_CLASSES; ++c) if (has[c]) top = c;
-    bool generic = false;
-    for (int c = 0; c <= top; ++c) {
-        if (!REV && !has[c]) continue;
-        if (c <= IPX_MAX_EXACT) ipx_launch_dp_class<BE, W, REV, LOW>(be, b, p, c, maxcols, kclass, pass);
-        else generic = true;
+    if (top < 0) return;
+    uint64_t exact = 0;                                           // classes with their own launch
+    for (int c = 0; c <= top && c <= IPX_MAX_EXACT; ++c) {
+        const bool own = REV ? (has[c] || (c + 1 <= top && has[c + 1])) : has[c] != 0;
+        if (own) { exact |= 1ull << c; ipx_launch_dp_class<BE, W, REV, LOW>(be, b, p, c, maxcols, kclass, pass); }
     }
-    if (generic)
+    bool rest = false;                                            // anything the exact launches do not cover?
+    for (int c = 0; c <= top; ++c)
+        if ((REV || has[c]) && !(c < 64 && ((exact >> c) & 1ull))) rest = true;
+    if (rest)
         be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.dp_grid(), 64,
-                  ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, IPX_MAX_EXACT + 1, IPX_MAX_SEG, maxcols, pass);
+                  ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
 }
 
 template <class BE>
