@@ -22,13 +22,18 @@ import sys
 
 
 def load(d, counter):
-    agg = collections.defaultdict(lambda: [0, 0.0])
+    """per kernel: [launches counted, sum] over the launches that did real work (>= 20 % of the kernel's
+    largest launch: the same instantiation is also launched for passes that turn out empty)"""
+    vals = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                a = agg[r["Kernel_Name"]]
-                a[0] += 1
-                a[1] += float(r["Counter_Value"])
+                vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    agg = {}
+    for k, v in vals.items():
+        top = max(v)
+        real = [x for x in v if x >= 0.2 * top] or v
+        agg[k] = [len(real), sum(real)]
     return agg
 
 
