@@ -239,10 +239,12 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 // Block = one wavefront (64 threads); grid-stride over the tiles of classes [cls_lo, cls_hi].
 // Dynamic LDS: profile 640*SMAX B | matrix 32 B.   Global: column maxima, 4*G*maxcols B per block (forward only)
 // ------------------------------------------------------------------------------------------------
-//   LOW  = first stage of the 8-bit forward pass: lazy-F carries that could meet the reference's
-//          signed-byte exit test (>= 128+gapE) are dropped instead of stepped.  The result is a lower
-//          bound of the exact pass, so "overflow" is certain; reads that neither overflowed nor lost
-//          a carry are exact; the rest are re-run by the exact instantiation (IPX_MODE_NEED_BYTE_EXACT).
+//   LOW  = first stage of the 8-bit forward pass: in a column where some lazy-F carry of a read could
+//          meet the reference's signed-byte exit test (>= 128+gapE), that read's whole lazy-F step is
+//          skipped instead of stepped.  H then is a lower bound of the exact pass (lazy-F only ever
+//          raises H, and the recurrences are monotone), so "overflow" is certain; reads that neither
+//          overflowed nor skipped a column are exact; the rest are re-run by the exact instantiation
+//          (IPX_MODE_NEED_BYTE_EXACT).
 template <int W, int SMAX, bool REV, bool EXACT, bool LOW>
 IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
 {
@@ -435,8 +437,13 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 pk16 fe = fast_static;
                 if (BYTE) {
                     const pk16 big = pk_nzmask(pk_subus(vF, bigthr));
-                    if (LOW) { const pk16 drop = big & fast_static; vF &= ~drop; dropped |= drop; }
-                    else fe &= ~group_or<W>(big);
+                    const pk16 anybig = group_or<W>(big);
+                    // LOW: a read with such a carry in this column gets NO lazy-F at all here (H stays the
+                    // main loop's value, which the reference's loop can only raise): dropping just the big
+                    // carry would not be a lower bound, because the reference's early exit also cuts the
+                    // small carries that the big one happened to dominate
+                    if (LOW) { const pk16 drop = anybig & fast_static; vF &= ~drop; dropped |= drop; }
+                    else fe &= ~anybig;
                 }
                 pk16 x = xl_row_shr1(vF & fe);
                 if (W == 8 && l == 0) x = 0;
