@@ -245,7 +245,13 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          raises H, and the recurrences are monotone), so "overflow" is certain; reads that neither
 //          overflowed nor skipped a column are exact; the rest are re-run by the exact instantiation
 //          (IPX_MODE_NEED_BYTE_EXACT).
-template <int W, int SMAX, bool REV, bool EXACT, bool LOW>
+//   PERM = the query profile is not staged in LDS: every striped row keeps a v_perm_b32 selector of its
+//          two read letters in a register, and a column's scores come from an 8-byte table
+//          {mat[c0][A..T], mat[c1][A..T]} of the two window letters: one v_perm_b32 puts the selected
+//          bytes in the high byte of each half and one packed arithmetic shift sign-extends them.
+//          Read letter N and padding rows select the constant 0, so this needs mat[c][N] == 0 for every
+//          c (true for indelPost's matrix, sswpy.pyx:306-336).  No LDS traffic in the column loop.
+template <int W, int SMAX, bool REV, bool EXACT, bool LOW, bool PERM = false>
 IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
@@ -255,11 +261,13 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
     unsigned char *lds = IPX_LDS_BASE;
-    int8_t *prof = (int8_t *)lds;                                  // [5][S][64][2]
-    int8_t *matl = (int8_t *)(lds + 640 * SA);
+    int8_t *prof = (int8_t *)lds;                                  // [5][S][64][2]      (!PERM)
+    const uint32_t *tab8 = (const uint32_t *)lds;                  // [5 window letters][4 int8]   (PERM)
+    int8_t *matl = (int8_t *)(lds + (PERM ? 64 : 640 * SA));
     uint32_t *maxcol = b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);   // this block's column maxima
 
     if (lane < 25) matl[lane] = b.mat[lane];
+    if (PERM && lane < 20) ((int8_t *)lds)[lane] = b.mat[(lane >> 2) * 5 + (lane & 3)];
     IPX_SYNC();
 
     const uint32_t tile_begin = p.tile_off[cls_lo], tile_end = p.tile_off[cls_hi + 1];
@@ -328,6 +336,39 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
         }
 
         // ---- stage the tile's query profile in LDS: int8 [5 letters][S][64 lanes][2 halves] ------------
+        pk16 SEL[PERM ? SA : 1];                                   // PERM: per striped row, byte selectors of the two read letters
+        if (PERM) {
+            // all letter loads of the tile are issued back to back (clamped addresses, no branches) ...
+            int raw[2][SA];
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j) {
+                    if (j < S) {
+                        const int r = j + l * S;                   // striped row (ssw.c:178-185)
+                        int idx = r < L[h] ? r : L[h] - 1;
+                        if (REV) idx = L[h] - 1 - idx;             // reverse pass: seq_reverse (ssw.c:774-785)
+                        raw[h][j] = load_stream_i8(L[h] > 0 ? rd[h] + idx : (const int8_t *)b.read_off);
+                    }
+                }
+            }
+            // ... then turned into selectors
+            IPX_UNROLL
+            for (int j = 0; j < SMAX; ++j) {
+                if (j < S) {
+                    const int r = j + l * S;
+                    uint32_t sel = 0;
+                    IPX_UNROLL
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned base = (unsigned)raw[h][j];
+                        uint32_t sh = 0x0c0cu;                     // padding row / letter N: constant 0
+                        if (r < L[h] && base < 4u) sh = 0x000cu | ((base + 4u * h) << 8);   // high byte <- table byte 4*h + base
+                        sel |= sh << (16 * h);
+                    }
+                    SEL[j] = sel;
+                }
+            }
+        } else {
         IPX_SYNC();   // previous tile's finalisation reads are done
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
@@ -343,6 +384,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             }
         }
         IPX_SYNC();
+        }
 
         // ---- DP state -----------------------------------------------------------------------------
         pk16 H[SA], E[SA], HM[SA];
@@ -360,22 +402,35 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
             if (k1 < 0) k1 = 0;
             if (k1 > kmax[h]) k1 = kmax[h];
-            cur[h] = refw[h][k0 > kmax[h] ? kmax[h] : k0];
-            nxt[h] = refw[h][k1];
+            cur[h] = load_global_u32(refw[h] + (k0 > kmax[h] ? kmax[h] : k0));
+            nxt[h] = load_global_u32(refw[h] + k1);
         }
 
-        for (int t = 0; t < T; ++t) {
-            // -- window letters of this column, 4 columns per loaded dword ---------------------------
-            if ((t & 3) == 0 && t > 0) {
-                IPX_UNROLL
-                for (int h = 0; h < 2; ++h) {
-                    cur[h] = nxt[h];
-                    int k = REV ? (idx0[h] >> 2) - ((t >> 2) + 1) : (t >> 2) + 1;
-                    if (k < 0) k = 0;
-                    if (k > kmax[h]) k = kmax[h];
-                    nxt[h] = refw[h][k];
-                }
-            }
+        // Columns go in groups of four = one dword of window letters.  All global-memory traffic of the
+        // column loop sits at the top of a group: the dword fetched one group ahead is consumed, the next
+        // one is requested and the previous group's four column maxima are stored -- so the only wait on
+        // global memory is for operations issued a whole group (thousands of cycles) earlier.
+        bool stop = false;
+        int tdone = -1;                                             // last column processed
+        pk16 cm4 = 0;                                               // lane l<4: maximum of column (group base + l)
+        for (int t0 = 0; t0 < T && !stop; t0 += 4) {
+          if (t0 > 0) {
+              IPX_UNROLL
+              for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
+              IPX_VMEM_FENCE();
+              IPX_UNROLL
+              for (int h = 0; h < 2; ++h) {
+                  int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 1) : (t0 >> 2) + 1;
+                  if (k < 0) k = 0;
+                  if (k > kmax[h]) k = kmax[h];
+                  nxt[h] = load_global_u32(refw[h] + k);
+              }
+              if (!REV && l < 4) store_global_u32(maxcol + ((t0 - 4 + l) * G + g), cm4);
+          }
+          const int tn = t0 + 4 < T ? t0 + 4 : T;
+          IPX_NOUNROLL
+          for (int t = t0; t < tn; ++t) {
+            tdone = t;
             const uint32_t sh = (uint32_t)(REV ? 3 - (t & 3) : (t & 3)) * 8u;
             uint32_t c[2];
             pk16 act = 0;
@@ -400,30 +455,40 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             }
             const int8_t *pa0 = prof + ((int)c[0] * S * 64 + lane) * 2;
             const int8_t *pa1 = prof + ((int)c[1] * S * 64 + lane) * 2 + 1;
+            uint32_t tab0 = 0, tab1 = 0;
+            if (PERM) { tab0 = tab8[c[0]]; tab1 = tab8[c[1]]; }
 
             // -- striped inner loop (ssw.c:274-299 / 480-504) -----------------------------------------
             pk16 vH = xl_row_shr1(Hlast);                         // _mm_slli_si128(pvHStore[segLen-1], 1|2)
             if (W == 8 && l == 0) vH = 0;
             pk16 vF = 0, cmx = 0;
-            IPX_UNROLL
-            for (int j = 0; j < SMAX; ++j) {
-                if (j < S) {
-                    const pk16 pp = pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]);
-                    pk16 h = pk_add_sat(vH, pp);
-                    pk16 e = E[j];
-                    h = pk_max(h, e);
-                    h = pk_max(h, vF);
-                    cmx = pk_max(cmx, h);
-                    vH = H[j];
-                    H[j] = h;
-                    if (j == S - 1) Hlast = h;
-                    const pk16 tt = pk_subus(h, go);
-                    e = pk_subus(e, ge);
-                    E[j] = pk_max(e, tt);
-                    vF = pk_subus(vF, ge);
-                    vF = pk_max(vF, tt);
-                }
+#define IPX_DP_STRIPE(PP)                                                                                    \
+            IPX_UNROLL                                                                                       \
+            for (int j = 0; j < SMAX; ++j) {                                                                 \
+                if (j < S) {                                                                                 \
+                    const pk16 pp = (PP);                                                                    \
+                    pk16 h = pk_add_sat(vH, pp);                                                             \
+                    pk16 e = E[j];                                                                           \
+                    h = pk_max(h, e);                                                                        \
+                    h = pk_max(h, vF);                                                                       \
+                    cmx = pk_max(cmx, h);                                                                    \
+                    vH = H[j];                                                                               \
+                    H[j] = h;                                                                                \
+                    if (j == S - 1) Hlast = h;                                                               \
+                    const pk16 tt = pk_subus(h, go);                                                         \
+                    e = pk_subus(e, ge);                                                                     \
+                    E[j] = pk_max(e, tt);                                                                    \
+                    vF = pk_subus(vF, ge);                                                                   \
+                    vF = pk_max(vF, tt);                                                                     \
+                    if (PERM) IPX_SCHED_FENCE();                                                             \
+                }                                                                                            \
             }
+            if (!PERM) {
+                IPX_DP_STRIPE(pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]))
+            } else {
+                IPX_DP_STRIPE(pk_sext_hi8(pk_perm(tab1, tab0, SEL[PERM ? j : 0])))
+            }
+#undef IPX_DP_STRIPE
 
             // -- lazy-F (ssw.c:302-313 / 507-518) --------------------------------------------------------
             // The reference passes each lane's final F to the next lane, walks the segments applying
@@ -447,7 +512,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 }
                 pk16 x = xl_row_shr1(vF & fe);
                 if (W == 8 && l == 0) x = 0;
-                if (xl_any(x != 0)) {
+                {   // (unconditional: a carry-free column is rare, and a branch here costs a copy of every H register)
                     pk16 y;
                     y = xl_row_shr<1>(x); if (W == 8 && l < 1) y = 0; x = pk_max(x, pk_subus(y, D1));
                     y = xl_row_shr<2>(x); if (W == 8 && l < 2) y = 0; x = pk_max(x, pk_subus(y, D2));
@@ -506,7 +571,7 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
                 for (int j = 0; j < SMAX; ++j)
                     if (j < S) HM[j] = pk_select(m, H[j], HM[j]);                    // pvHmax (ssw.c:331 / 533)
             }
-            if (!REV) { if (l == 0) maxcol[t * G + g] = cmA; }
+            if (!REV) cm4 = (l == (t & 3)) ? cmA : cm4;
             ovf |= om;
             done |= om;
             if (REV) done |= (~pk_nzmask(cmA ^ term)) & a2;                          // maxColumn[i] == terminate
@@ -515,8 +580,10 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
             IPX_UNROLL
             for (int h = 0; h < 2; ++h)
                 alive = alive || ((t + 1 < tb[h] + ncol[h]) && ((done >> (16 * h)) & 0xFFFFu) == 0);
-            if (!xl_any(alive)) break;
+            if (!xl_any(alive)) { stop = true; break; }
+          }
         }
+        if (!REV && tdone >= 0 && l <= (tdone & 3)) store_global_u32(maxcol + (((tdone & ~3) + l) * G + g), cm4);   // last group
 
         // ---- finalisation ---------------------------------------------------------------------------
         IPX_SYNC();   // column maxima written by lane 0 of each group (global scratch, same wave) are visible to the group
@@ -593,15 +660,32 @@ IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, in
 // the 8-bit matrix is >= the ungapped local score of its diagonal (H = max(diag + P, E, F) >= diag + P
 // and >= 0, up to the first saturation), so if the best ungapped run on the diagonal through the
 // 16-bit end point reaches 255-bias, the 8-bit pass is certain to leave with 255 and the 16-bit
-// result is the answer.  One lane per read, O(readLen).  Unproven reads take the 8-bit pass as usual.
+// result is the answer.  One lane per read, O(readLen).
+//
+// Reads that fail the ungapped test (an indel splits their matches) get a GAPPED lower bound over a
+// band of IPX_PROVE_BAND diagonals around the end diagonal, built only from moves whose value the 8-bit
+// pass is certain to contain whatever its lazy-F loop does (ssw.c:302-313 leaves early on a signed
+// compare, so a vertical gap that crosses a segment boundary may be lost there):
+//   diagonal steps; horizontal gaps (E is updated from the main loop's H, ssw.c:286-291); vertical gaps
+//   that stay inside one segment of the striped layout, i.e. never INTO a row r with r % segLen == 0
+//   (inside a segment F comes from the main loop itself, ssw.c:294-296).
+// Cells outside the band or the window count as 0, which only lowers the bound.  If the bound reaches
+// 255-bias the 8-bit pass overflows.  Still-unproven reads take the 8-bit pass as usual.
 // ------------------------------------------------------------------------------------------------
+#define IPX_PROVE_BAND 15
 IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap)
 {
     // 64 consecutive jobs per wavefront: their reads are contiguous in HBM, so the wave copies them into
     // LDS with coalesced loads and every lane then walks its own read there (the per-lane backwards byte
     // walk straight from HBM fetched ~6 KB per read).  Batches that do not fit `lds_cap` fall back to HBM.
     const int lane = lane_id();
-    int8_t *stage = (int8_t *)IPX_LDS_BASE;
+    uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
+    int8_t *stage = (int8_t *)IPX_LDS_BASE + 64;
+    if (lane < 5) {
+        uint64_t t = 0;
+        for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
+        coltab[lane] = t;
+    }
     const int64_t nb = (b.n_jobs + 63) / 64;
     for (int64_t blk = IPX_BID; blk < nb; blk += IPX_GDIM) {
         const int64_t i0 = blk * 64, i = i0 + lane;
@@ -627,6 +711,57 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap)
             u += b.mat[c * 5 + a];
             if (u < 0) u = 0;
             if (u >= cap) proven = true;
+        }
+        if (!proven) {
+            constexpr int BW = IPX_PROVE_BAND, HB = BW / 2;
+            const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+            const int S8 = (Lr + 15) >> 4;                         // segLen of the 8-bit pass (ssw.c:166)
+            const int refLen = b.ref_len[rid];
+            const int d0 = r.ref_end1 - r.read_end1;               // column - row of the end diagonal
+            const int go = b.gap_open[i], ge = b.gap_ext[i];
+            int H[BW], F[BW];                                      // previous row: cell k is column (row + d0 - HB + k)
+            IPX_UNROLL
+            for (int k = 0; k < BW; ++k) { H[k] = 0; F[k] = 0; }
+            uint64_t win = 0;                                      // 4 bits per band cell: window letter, 7 = outside the window
+            IPX_UNROLL
+            for (int k = 0; k < BW; ++k) {
+                const int c = d0 - HB + k;
+                const uint64_t cl = (c >= 0 && c < refLen) ? (uint64_t)(uint8_t)rf[c] : 7u;
+                win |= cl << (4 * k);
+            }
+            int seg = 0;                                           // row % segLen
+            for (int rr = 0; rr <= r.read_end1 && !proven; ++rr) {
+                int a = rd[rr];
+                if ((unsigned)a > 4u) a = 4;
+                const uint64_t row = coltab[a];
+                const bool fopen = seg != 0;                       // a vertical gap may enter this row
+                int e = 0, hleft = 0;
+                IPX_UNROLL
+                for (int k = 0; k < BW; ++k) {
+                    const unsigned cl = (unsigned)(win >> (4 * k)) & 7u;
+                    int f = 0;
+                    if (fopen && k + 1 < BW) {
+                        const int f1 = F[k + 1] - ge, f2 = H[k + 1] - go;
+                        f = f1 > f2 ? f1 : f2;
+                        if (f < 0) f = 0;
+                    }
+                    {
+                        const int e1 = e - ge, e2 = hleft - go;
+                        e = e1 > e2 ? e1 : e2;
+                        if (e < 0) e = 0;
+                    }
+                    int h = H[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
+                    if (h < e) h = e;
+                    if (h < f) h = f;
+                    if (cl > 4u) { h = 0; e = 0; f = 0; }            // outside the window
+                    if (h >= cap) proven = true;
+                    H[k] = h; F[k] = f; hleft = h;
+                }
+                const int cn = rr + 1 + d0 + HB;                   // column entering the band on the next row
+                const uint64_t cl = (cn >= 0 && cn < refLen) ? (uint64_t)(uint8_t)rf[cn] : 7u;
+                win = (win >> 4) | (cl << (4 * (BW - 1)));
+                if (++seg == S8) seg = 0;
+            }
         }
         r.mode = proven ? IPX_MODE_WORD : IPX_MODE_NEED_BYTE_CHECK;
         b.res[i] = r;

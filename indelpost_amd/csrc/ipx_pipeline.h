@@ -46,11 +46,18 @@ enum {
     IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_WORD_FIRST, IPX_K_PROVE, IPX_K_NUM
 };
 
-static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols)
+static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm = false)
 {
     static const int extra = getenv("IPX_DEBUG_EXTRA_LDS") ? atoi(getenv("IPX_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
     (void)W; (void)rev; (void)maxcols;
-    return 640 * (SMAX > 0 ? SMAX : 1) + 64 + extra;
+    return (perm ? 64 : 640 * (SMAX > 0 ? SMAX : 1)) + 64 + extra;
+}
+
+// the register-selector profile (k_dp_pass PERM) needs a read letter N to score 0 against every window letter
+static inline bool ipx_perm_profile_ok(const int8_t *mat)
+{
+    static const bool off = getenv("IPX_NO_PERM_PROFILE") != nullptr;
+    return !off && mat[4] == 0 && mat[9] == 0 && mat[14] == 0 && mat[19] == 0 && mat[24] == 0;
 }
 
 // timing key of a launch: kernel class * 128 + sub (DP kernels: sub = segLen, 65 = long-read kernel)
@@ -63,9 +70,14 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 {
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
-        be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW>, be.dp_grid(), 64,                          \
-                  ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);                                \
+        if (perm)                                                                                            \
+            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, true>, be.dp_grid(), 64,           \
+                      ipx_dp_lds_bytes(W, N, REV, maxcols, true), b, p, N, N, maxcols, pass, (uint64_t)0);   \
+        else                                                                                                 \
+            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, false>, be.dp_grid(), 64,          \
+                      ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);         \
         break;
+    const bool perm = ipx_perm_profile_ok(b.mat);
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
         IPX_DP_CASE(7) IPX_DP_CASE(8) IPX_DP_CASE(9) IPX_DP_CASE(10) IPX_DP_CASE(11) IPX_DP_CASE(12) IPX_DP_CASE(13)

@@ -15,12 +15,18 @@ typedef uint32_t pk16; // two 16-bit DP cells: lo half = even alignment slot, hi
 // lock-step emulation (tests only)
 // ------------------------------------------------------------------------------------------------
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+struct uint2 { uint32_t x, y; };
 #define IPX_KERNEL
 #define IPX_KERNEL_WAVE
 #define IPX_KERNEL_WAVE_OCC(w)
 #define IPX_DEV static inline
 #define IPX_HD static inline
 #define IPX_UNROLL
+#define IPX_SCHED_FENCE() ((void)0)
+#define IPX_VMEM_FENCE() ((void)0)
+#define IPX_NOUNROLL
 #define IPX_RESTRICT
 namespace ipx_emu {
 struct LaneCtx { int tid; int bid; int gdim; int bdim; unsigned char *lds; };
@@ -72,7 +78,26 @@ IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return (v >> o
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b)
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
 IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte table {hi:lo} (0..3 = lo, 4..7 = hi), 0x0c = constant 0
+IPX_DEV uint32_t pk_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const uint64_t t = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (sel >> (8 * i)) & 0xFFu;
+        uint32_t v;
+        if (k < 8u) v = (uint32_t)(t >> (8 * k)) & 0xFFu;
+        else if (k == 0x0cu) v = 0u;
+        else { fprintf(stderr, "emu: pk_perm selector %#x not modelled\n", k); abort(); }
+        r |= v << (8 * i);
+    }
+    return r;
+}
+// per half: the signed high byte, sign-extended to 16 bit (v_pk_ashrrev_i16 by 8)
+IPX_DEV pk16 pk_sext_hi8(pk16 x) { return pk_make(pk_lo(x) >> 8, pk_hi(x) >> 8); }
 IPX_DEV int8_t load_stream_i8(const int8_t *p) { return *p; }
+IPX_DEV uint32_t load_global_u32(const uint32_t *p) { return *p; }
+IPX_DEV void store_global_u32(uint32_t *p, uint32_t v) { *p = v; }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 
@@ -87,6 +112,11 @@ IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 #define IPX_DEV __device__ __forceinline__
 #define IPX_HD __host__ __device__ inline
 #define IPX_UNROLL _Pragma("unroll")
+// keep the instruction scheduler from moving anything across this point (register pressure control)
+#define IPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// wait for every outstanding global-memory operation here, and keep later ones below this point
+#define IPX_VMEM_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define IPX_NOUNROLL _Pragma("unroll 1")
 #define IPX_RESTRICT __restrict__
 #define IPX_TID ((int)threadIdx.x)
 #define IPX_BID ((int)blockIdx.x)
@@ -128,12 +158,18 @@ IPX_DEV pk16 pk_sub(pk16 a, pk16 b) { return IPX_PK(IPX_S2(a) - IPX_S2(b)); }   
 IPX_DEV pk16 pk_subus(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_sub_sat(IPX_U2(a), IPX_U2(b))); }      // v_pk_sub_u16 clamp
 IPX_DEV pk16 pk_max(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_max(IPX_S2(a), IPX_S2(b))); }            // v_pk_max_i16
 IPX_DEV pk16 pk_minu(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_min(IPX_U2(a), IPX_U2(b))); }           // v_pk_min_u16
+IPX_DEV pk16 pk_sext_hi8(pk16 x) { return IPX_PK(IPX_S2(x) >> 8); }   // per half: signed high byte -> 16 bit: v_pk_ashrrev_i16
 IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b): one v_perm_b32
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// byte table lookup: result byte i = byte sel[i] of {hi:lo} (0..3 = lo, 4..7 = hi), selector 0x0c = constant 0
+IPX_DEV uint32_t pk_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // read-once data (the read letters): keep it out of the way of the L2-resident per-block scratch
 IPX_DEV int8_t load_stream_i8(const int8_t *p) { return __builtin_nontemporal_load(p); }
+// explicitly global (not flat) accesses: they count in vmcnt only, so LDS waits do not wait for them
+IPX_DEV uint32_t load_global_u32(const uint32_t *p) { return *(const __attribute__((address_space(1))) uint32_t *)p; }
+IPX_DEV void store_global_u32(uint32_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t *)p = v; }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 #endif
