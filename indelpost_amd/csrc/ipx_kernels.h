@@ -138,10 +138,12 @@ IPX_DEV int plan_class(const IpxBatch &b, int pass, int64_t i)
         break;
     case IPX_PASS_BYTE_FWD:
         if (b.score_size == 1 || (r.mode != IPX_MODE_PENDING && r.mode != IPX_MODE_NEED_BYTE_CHECK)) return -1;
+        if (r.mode == IPX_MODE_PENDING && readLen < b.byte_safe_len) return -1;      // cannot overflow: exact stage directly
         L = readLen; lanes = 16; ncol = refLen;
         break;
     case IPX_PASS_BYTE_FWD_EXACT:
-        if (r.mode != IPX_MODE_NEED_BYTE_EXACT && r.mode != IPX_MODE_NEED_BYTE_EXACT_W) return -1;
+        if (r.mode != IPX_MODE_NEED_BYTE_EXACT && r.mode != IPX_MODE_NEED_BYTE_EXACT_W &&
+            !(r.mode == IPX_MODE_PENDING && b.score_size != 1 && readLen < b.byte_safe_len)) return -1;
         L = readLen; lanes = 16; ncol = refLen;
         break;
     case IPX_PASS_WORD_FWD:
@@ -251,8 +253,16 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          bytes in the high byte of each half and one packed arithmetic shift sign-extends them.
 //          Read letter N and padding rows select the constant 0, so this needs mat[c][N] == 0 for every
 //          c (true for indelPost's matrix, sswpy.pyx:306-336).  No LDS traffic in the column loop.
+// With the profile out of LDS the register file alone sets the occupancy: ask for 4 waves per SIMD
+// (128 VGPRs).  What does not fit is per-tile setup/finalisation data, spilled outside the column loop.
+// (state = H, E, Hmax and the selectors = 4 registers per segment, ~52 for everything else.)
+IPX_HD constexpr int ipx_dp_perm_waves(int smax)
+{
+    const int w = 512 / (4 * smax + 52);
+    return w < 2 ? 2 : (w > 6 ? 6 : w);
+}
 template <int W, int SMAX, bool REV, bool EXACT, bool LOW, bool PERM = false>
-IPX_KERNEL_WAVE void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
+IPX_KERNEL_WAVE_OCC(PERM ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;

@@ -46,6 +46,7 @@ enum {
     IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_WORD_FIRST, IPX_K_PROVE, IPX_K_NUM
 };
 
+#define IPX_DP_WAVES_PER_CU 24      // DP grid cap: 6 waves per SIMD is the most any DP kernel asks for
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm = false)
 {
     static const int extra = getenv("IPX_DEBUG_EXTRA_LDS") ? atoi(getenv("IPX_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
@@ -56,7 +57,7 @@ static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool 
 // the register-selector profile (k_dp_pass PERM) needs a read letter N to score 0 against every window letter
 static inline bool ipx_perm_profile_ok(const int8_t *mat)
 {
-    static const bool off = getenv("IPX_NO_PERM_PROFILE") != nullptr;
+    const bool off = getenv("IPX_NO_PERM_PROFILE") != nullptr;   // (looked up per launch: the tests flip it)
     return !off && mat[4] == 0 && mat[9] == 0 && mat[14] == 0 && mat[19] == 0 && mat[24] == 0;
 }
 
@@ -192,6 +193,15 @@ static inline int ipx_word_first_len(const int8_t *mat, int bias)
     if (mx <= 0) return 0;
     const int cap = 255 - bias;
     return (cap * 14 / 10 + mx - 1) / mx;
+}
+
+// shortest read that could overflow the 8-bit pass: len * max(mat) >= 255 - bias
+static inline int ipx_byte_safe_len(const int8_t *mat, int bias)
+{
+    int mx = 0;
+    for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
+    if (mx <= 0) return 0x7FFFFFFF;
+    return (255 - bias + mx - 1) / mx;
 }
 
 // scratch sizing shared by both back-ends -------------------------------------------------------

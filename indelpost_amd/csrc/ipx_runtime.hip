@@ -88,7 +88,7 @@ struct HipBackend {
     int dp_grid() const
     {
         int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
-        const int64_t cap = (int64_t)c->num_cu * 12;       // ~ the resident wave count: per-block scratch stays L2-sized
+        const int64_t cap = (int64_t)c->num_cu * IPX_DP_WAVES_PER_CU;   // ~ the resident wave count: per-block scratch stays L2-sized
         return (int)(g < cap ? g : cap);
     }
     int flat_grid(int64_t n) const
@@ -293,7 +293,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb1.cig = (uint32_t *)(c->tb1.as<char>() + (size_t)c->ws.tb1.dircap * (size_t)w1);
 
     // column-maxima scratch of the forward passes: one region per DP block
-    if (c->maxcol.ensure((size_t)c->num_cu * 12 * 16 * (size_t)(d.max_ref_len + 8) * 4)) return IPX_ERR_NO_DEVICE;
+    if (c->maxcol.ensure((size_t)c->num_cu * IPX_DP_WAVES_PER_CU * 16 * (size_t)(d.max_ref_len + 8) * 4)) return IPX_ERR_NO_DEVICE;
 
     // small tables
     uint32_t *sm = c->small.as<uint32_t>();
@@ -333,6 +333,7 @@ int ipx_run(ipx_ctx *c)
     IpxBatch &b = c->batch;
     memcpy(b.mat, c->mat, 25);
     b.word_first_len = getenv("IPX_NO_WORD_FIRST") ? 0 : ipx_word_first_len(c->mat, c->bias);
+    b.byte_safe_len = getenv("IPX_NO_BYTE_SAFE") ? 0 : ipx_byte_safe_len(c->mat, c->bias);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;

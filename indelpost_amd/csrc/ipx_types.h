@@ -63,6 +63,8 @@ struct IpxBatch {
     int8_t mat[25];             // 5x5 substitution matrix (sswpy.pyx:306-336)
     int32_t bias;               // |min(mat)| (ssw.c:795-799)
     int32_t word_first_len;     // reads at least this long take the 16-bit pass first (0 = never); speed only
+    int32_t byte_safe_len;      // reads shorter than this cannot reach 255-bias (len * max(mat) < 255-bias): they skip the
+                                //   lower-bound stage of the 8-bit pass, whose only gain is a cheap overflow verdict; speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)
     uint16_t filters;

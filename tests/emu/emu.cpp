@@ -203,6 +203,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     for (int k = 0; k < 25; ++k) if (mat[k] < bias) bias = mat[k];
     b.bias = -bias;
     b.word_first_len = getenv("IPX_NO_WORD_FIRST") ? 0 : ipx_word_first_len(mat, -bias);
+    b.byte_safe_len = getenv("IPX_NO_BYTE_SAFE") ? 0 : ipx_byte_safe_len(mat, -bias);
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
 

@@ -151,3 +151,24 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
     mat = oracle_mod.dna_matrix(2, 2)
     for i in range(4):
         assert res.as_dict(i) == port.align(reads[i], w, mat, 3, 1, mask_len=masks[i]), i
+
+
+@pytest.mark.parametrize("knobs", [("IPX_NO_BYTE_SAFE",), ("IPX_NO_PERM_PROFILE",),
+                                   ("IPX_NO_WORD_FIRST", "IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE")])
+def test_emu_routing_knobs_off(emu, golden_c, monkeypatch, knobs):
+    """The speed-only routing decisions (skip the lower-bound stage for reads that cannot overflow, 16-bit
+    pass first, register-selector profile) must not change any result: golden vectors with each turned off."""
+    for k in knobs:
+        monkeypatch.setenv(k, "1")
+    groups = {}
+    for c in golden_c[160:320]:
+        groups.setdefault((c["match"], c["mismatch"]), []).append(c)
+    for (ms, mm), cs in groups.items():
+        a = emu(0, ms, mm)
+        jobs = JobTable.from_sequences([codes(c["read"]) for c in cs], [codes(c["ref"]) for c in cs],
+                                       np.arange(len(cs), dtype=np.int32), [c["gap_open"] for c in cs],
+                                       [c["gap_ext"] for c in cs], encoded=True)
+        res = a.align(jobs)
+        assert a.status == 0
+        for i, c in enumerate(cs):
+            assert res.as_dict(i) == c["expect"], "knobs %s scoring %s case %d" % (knobs, (ms, mm), i)

@@ -50,10 +50,16 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True):
     return JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
 
 
-@pytest.mark.parametrize("scoring", [(3, 2), (1, 1), (2, 2), (1, 3), (5, 4), (2, 4)])
-def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, capfd):
+# the last two cases repeat a scoring with the speed-only routing decisions turned off (lower-bound
+# 8-bit stage for every read, 8-bit pass before the 16-bit one, LDS-staged profile): same results required
+@pytest.mark.parametrize("scoring,knobs", [((3, 2), ()), ((1, 1), ()), ((2, 2), ()), ((1, 3), ()), ((5, 4), ()), ((2, 4), ()),
+                                           ((1, 1), ("IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE")),
+                                           ((3, 2), ("IPX_NO_WORD_FIRST", "IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE"))])
+def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd, monkeypatch):
     from oracle.oracle import cpu_batch_results, fnv1a_ops
-    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1])
+    for k in knobs:
+        monkeypatch.setenv(k, "1")
+    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs))
     n = int(os.environ.get("IPX_STRESS_JOBS", "30000"))
     jobs = _make_jobs(rng, n, 97)
     be = oracle_mod.Backend("reference" if oracle_mod.have_reference() else "port")
