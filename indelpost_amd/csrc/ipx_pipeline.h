@@ -46,7 +46,17 @@ enum {
     IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_WORD_FIRST, IPX_K_PROVE, IPX_K_NUM
 };
 
-#define IPX_DP_WAVES_PER_CU 24      // DP grid cap: 6 waves per SIMD is the most any DP kernel asks for
+// DP grid cap, in blocks (= waves) per CU.  Far more than are resident (<= 24): with several streams
+// sharing the GPU, short-lived blocks let the kernels of different streams interleave and even out the
+// tail (measured on config 2b, 4 streams: 12 -> 41.4, 24 -> 42.5, 48 -> 43.3, 96 -> 43.6 M aln/s).
+// Each block owns a column-maxima scratch region, so the grid is also capped by IPX_DP_SCRATCH_BUDGET.
+#define IPX_DP_WAVES_PER_CU 64
+#define IPX_DP_SCRATCH_BUDGET ((size_t)1 << 30)
+static inline int ipx_dp_grid_mult()
+{
+    static const int m = getenv("IPX_DP_GRID_MULT") ? atoi(getenv("IPX_DP_GRID_MULT")) : IPX_DP_WAVES_PER_CU;   // tuning experiments
+    return m > 0 ? m : IPX_DP_WAVES_PER_CU;
+}
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm = false)
 {
     static const int extra = getenv("IPX_DEBUG_EXTRA_LDS") ? atoi(getenv("IPX_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments

@@ -78,6 +78,7 @@ struct ipx_ctx {
     int k_launches[IPX_NUM_KEYS];
     hipEvent_t run_start = nullptr, run_stop = nullptr;
     float last_run_ms = 0.f;
+    int64_t dp_grid_cap = 1;                    // DP blocks per launch (each owns a column-maxima scratch region)
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
 };
 
@@ -87,9 +88,8 @@ struct HipBackend {
     hipError_t err = hipSuccess;
     int dp_grid() const
     {
-        int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
-        const int64_t cap = (int64_t)c->num_cu * IPX_DP_WAVES_PER_CU;   // ~ the resident wave count: per-block scratch stays L2-sized
-        return (int)(g < cap ? g : cap);
+        const int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
+        return (int)(g < c->dp_grid_cap ? g : c->dp_grid_cap);
     }
     int flat_grid(int64_t n) const
     {
@@ -293,7 +293,14 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb1.cig = (uint32_t *)(c->tb1.as<char>() + (size_t)c->ws.tb1.dircap * (size_t)w1);
 
     // column-maxima scratch of the forward passes: one region per DP block
-    if (c->maxcol.ensure((size_t)c->num_cu * IPX_DP_WAVES_PER_CU * 16 * (size_t)(d.max_ref_len + 8) * 4)) return IPX_ERR_NO_DEVICE;
+    {
+        const size_t per_block = 16 * (size_t)(d.max_ref_len + 8) * 4;
+        int64_t cap = (int64_t)c->num_cu * ipx_dp_grid_mult();
+        const int64_t fit = (int64_t)(IPX_DP_SCRATCH_BUDGET / per_block), floor_ = (int64_t)c->num_cu * 24;   // never below the resident count
+        if (cap > fit) cap = fit > floor_ ? fit : floor_;
+        c->dp_grid_cap = cap;
+        if (c->maxcol.ensure((size_t)cap * per_block)) return IPX_ERR_NO_DEVICE;
+    }
 
     // small tables
     uint32_t *sm = c->small.as<uint32_t>();

@@ -22,7 +22,8 @@ def gen_windows_reads(n_windows, reads_per_window, rls, wl_lo, wl_hi, seed=synth
     return reads, refs, rid
 
 def run(tag, jobs, scoring, check=20000):
-    g=ip.GpuAligner(0,*scoring); g.upload(jobs)
+    streams=int(os.environ.get("STREAMS","1"))
+    g=(ip.MultiStreamAligner(0,*scoring,streams=streams) if streams>1 else ip.GpuAligner(0,*scoring)); g.upload(jobs)
     g.run(); g.sync()
     g.set_profiling(True)
     t0=time.perf_counter()
@@ -30,8 +31,9 @@ def run(tag, jobs, scoring, check=20000):
     g.sync(); dt=(time.perf_counter()-t0)/3
     kt=g.kernel_times()
     res=g.download()
-    print('   traceback routing (bw1..7, general, wide):', g.traceback_routing())
-    top=sorted(((v[0]/3,k) for k,v in kt.items()), reverse=True)[:6]
+    if streams==1: print('   traceback routing (bw1..7, general, wide):', g.traceback_routing())
+    top=sorted(((v[0]/3,k) for k,v in kt.items()), reverse=True)
+    top=[t for t in top if t[0]>=0.4]
     print("%s: n=%d  %.2f ms/step  %.2f M aln/s   top kernels: %s"%(tag, jobs.n_jobs, dt*1e3, jobs.n_jobs/dt/1e6, ", ".join("%s %.2f"%(k,t) for t,k in top)))
     print("   modes:", dict(zip(*np.unique(res.records['mode'],return_counts=True))), "flags:", dict(zip(*np.unique(res.records['flag'],return_counts=True))))
     # parity on a sample vs the CPU checker
