@@ -239,7 +239,8 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          !EXACT (long reads): S <= SMAX is read per tile and every segment step is branch-guarded
 //   REV  = reverse pass (reversed read prefix vs window prefix walked right to left, ssw.c:875-886)
 // Block = one wavefront (64 threads); grid-stride over the tiles of classes [cls_lo, cls_hi].
-// Dynamic LDS: profile 640*SMAX B | matrix 32 B.   Global: column maxima, 4*G*maxcols B per block (forward only)
+// Dynamic LDS: !PERM profile 640*SMAX B | matrix 32 B;  PERM table 64 B | matrix 64 B | column maxima 4*G*maxcols B when they fit.
+// Global: column maxima, 4*G*maxcols B per block, otherwise (forward only)
 // ------------------------------------------------------------------------------------------------
 //   LOW  = first stage of the 8-bit forward pass: in a column where some lazy-F carry of a read could
 //          meet the reference's signed-byte exit test (>= 128+gapE), that read's whole lazy-F step is
@@ -253,16 +254,18 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 //          bytes in the high byte of each half and one packed arithmetic shift sign-extends them.
 //          Read letter N and padding rows select the constant 0, so this needs mat[c][N] == 0 for every
 //          c (true for indelPost's matrix, sswpy.pyx:306-336).  No LDS traffic in the column loop.
-// With the profile out of LDS the register file alone sets the occupancy: ask for 4 waves per SIMD
-// (128 VGPRs).  What does not fit is per-tile setup/finalisation data, spilled outside the column loop.
-// (state = H, E, Hmax and the selectors = 4 registers per segment, ~52 for everything else.)
+// With the profile out of LDS the register file alone sets the occupancy.  The request below only nudges
+// the kernels that sit just above a waves-per-SIMD step (the reverse pass at segLen 17-19: 182 -> 170
+// VGPRs, 2 -> 3 waves).  Pushing harder (4 waves at segLen 19) was measured: +2 % speed for register
+// spills worth 3x the tile's input in memory traffic -- the DP is issue-bound, not latency-bound.
+// (state = H, E, Hmax and the selectors = 4 registers per segment.)
 IPX_HD constexpr int ipx_dp_perm_waves(int smax)
 {
-    const int w = 512 / (4 * smax + 52);
-    return w < 2 ? 2 : (w > 6 ? 6 : w);
+    const int w = 512 / (4 * smax + 90);
+    return w < 1 ? 1 : w;
 }
 template <int W, int SMAX, bool REV, bool EXACT, bool LOW, bool PERM = false>
-IPX_KERNEL_WAVE_OCC(PERM ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
+IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
 {
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
@@ -274,7 +277,11 @@ IPX_KERNEL_WAVE_OCC(PERM ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch 
     int8_t *prof = (int8_t *)lds;                                  // [5][S][64][2]      (!PERM)
     const uint32_t *tab8 = (const uint32_t *)lds;                  // [5 window letters][4 int8]   (PERM)
     int8_t *matl = (int8_t *)(lds + (PERM ? 64 : 640 * SA));
-    uint32_t *maxcol = b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);   // this block's column maxima
+    // this block's column maxima: in LDS when the launch reserved room for them (windows short enough to
+    // keep the occupancy), else in its region of the global scratch
+    const bool mc_lds = PERM && !REV && (pass & IPX_PASS_MC_LDS) != 0;
+    pass &= 0xFF;
+    uint32_t *maxcol = mc_lds ? (uint32_t *)(lds + 128) : b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);
 
     if (lane < 25) matl[lane] = b.mat[lane];
     if (PERM && lane < 20) ((int8_t *)lds)[lane] = b.mat[(lane >> 2) * 5 + (lane & 3)];
@@ -435,7 +442,7 @@ IPX_KERNEL_WAVE_OCC(PERM ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch 
                   if (k > kmax[h]) k = kmax[h];
                   nxt[h] = load_global_u32(refw[h] + k);
               }
-              if (!REV && l < 4) store_global_u32(maxcol + ((t0 - 4 + l) * G + g), cm4);
+              if (!REV && l < 4) { if (mc_lds) maxcol[(t0 - 4 + l) * G + g] = cm4; else store_global_u32(maxcol + ((t0 - 4 + l) * G + g), cm4); }
           }
           const int tn = t0 + 4 < T ? t0 + 4 : T;
           IPX_NOUNROLL
@@ -593,10 +600,34 @@ IPX_KERNEL_WAVE_OCC(PERM ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch 
             if (!xl_any(alive)) { stop = true; break; }
           }
         }
-        if (!REV && tdone >= 0 && l <= (tdone & 3)) store_global_u32(maxcol + (((tdone & ~3) + l) * G + g), cm4);   // last group
+        if (!REV && tdone >= 0 && l <= (tdone & 3)) {                                                             // last group
+            if (mc_lds) maxcol[((tdone & ~3) + l) * G + g] = cm4; else store_global_u32(maxcol + (((tdone & ~3) + l) * G + g), cm4);
+        }
 
         // ---- finalisation ---------------------------------------------------------------------------
         IPX_SYNC();   // column maxima written by lane 0 of each group (global scratch, same wave) are visible to the group
+        // The per-slot facts needed from here on are looked up AGAIN rather than kept alive across the column
+        // loop: kept alive they are spilled (one scratch dword per lane each), which costs more memory
+        // traffic per tile than the tile's whole input.
+        IPX_COMPILER_FENCE();
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int slot = 2 * g + h;
+            job[h] = -1; L[h] = 0; ncol[h] = 0; score1[h] = 0; rend1[h] = -1;
+            if (slot < cnt) {
+                const int64_t jb = (int64_t)p.perm[first + slot];
+                job[h] = jb;
+                if (!REV) {
+                    L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
+                    ncol[h] = b.ref_len[b.ref_id[jb]];
+                } else {
+                    const IpxResult r = b.res[jb];
+                    L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
+                    score1[h] = r.score1;
+                    rend1[h] = r.read_end1;
+                }
+            }
+        }
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
             // end position on the read: smallest striped row holding `best` in the saved column (ssw.c:340-349)

@@ -57,11 +57,17 @@ static inline int ipx_dp_grid_mult()
     static const int m = getenv("IPX_DP_GRID_MULT") ? atoi(getenv("IPX_DP_GRID_MULT")) : IPX_DP_WAVES_PER_CU;   // tuning experiments
     return m > 0 ? m : IPX_DP_WAVES_PER_CU;
 }
+// column maxima of a forward selector-profile kernel stay in LDS while 16 waves per CU still fit (160 KB)
+#define IPX_DP_MC_LDS_MAX 10112
+static inline bool ipx_dp_mc_in_lds(int W, bool rev, int maxcols, bool perm)
+{
+    return perm && !rev && (64 / W) * maxcols * 4 <= IPX_DP_MC_LDS_MAX && !getenv("IPX_NO_MC_LDS");
+}
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm = false)
 {
     static const int extra = getenv("IPX_DEBUG_EXTRA_LDS") ? atoi(getenv("IPX_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
-    (void)W; (void)rev; (void)maxcols;
-    return (perm ? 64 : 640 * (SMAX > 0 ? SMAX : 1)) + 64 + extra;
+    const int mc = ipx_dp_mc_in_lds(W, rev, maxcols, perm) ? (64 / W) * maxcols * 4 : 0;
+    return (perm ? 64 : 640 * (SMAX > 0 ? SMAX : 1)) + 64 + mc + extra;
 }
 
 // the register-selector profile (k_dp_pass PERM) needs a read letter N to score 0 against every window letter
@@ -83,7 +89,8 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
     case N:                                                                                                  \
         if (perm)                                                                                            \
             be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, true>, be.dp_grid(), 64,           \
-                      ipx_dp_lds_bytes(W, N, REV, maxcols, true), b, p, N, N, maxcols, pass, (uint64_t)0);   \
+                      ipx_dp_lds_bytes(W, N, REV, maxcols, true), b, p, N, N, maxcols,                       \
+                      pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true) ? IPX_PASS_MC_LDS : 0), (uint64_t)0);  \
         else                                                                                                 \
             be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, false>, be.dp_grid(), 64,          \
                       ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);         \

@@ -26,6 +26,7 @@ struct uint2 { uint32_t x, y; };
 #define IPX_UNROLL
 #define IPX_SCHED_FENCE() ((void)0)
 #define IPX_VMEM_FENCE() ((void)0)
+#define IPX_COMPILER_FENCE() ((void)0)
 #define IPX_NOUNROLL
 #define IPX_RESTRICT
 namespace ipx_emu {
@@ -117,6 +118,8 @@ IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 // wait for every outstanding global-memory operation here, and keep later ones below this point
 #define IPX_VMEM_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define IPX_NOUNROLL _Pragma("unroll 1")
+// the compiler may not carry memory values (or move memory operations) across this point
+#define IPX_COMPILER_FENCE() asm volatile("" ::: "memory")
 #define IPX_RESTRICT __restrict__
 #define IPX_TID ((int)threadIdx.x)
 #define IPX_BID ((int)blockIdx.x)

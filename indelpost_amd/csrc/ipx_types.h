@@ -40,6 +40,7 @@ enum {
     IPX_PASS_BYTE_FWD_EXACT = 4,
     IPX_PASS_WORD_FIRST = 5,      // 16-bit forward pass BEFORE the 8-bit one, for reads that will almost surely overflow
     IPX_NUM_PASSES = 6,
+    IPX_PASS_MC_LDS = 0x100,      // flag or-ed into a DP kernel's `pass` argument: column maxima live in LDS (room reserved by the launch)
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels

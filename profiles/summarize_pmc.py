@@ -38,7 +38,7 @@ def load(d, counter):
 
 
 def bench_name(k):
-    m = re.match(r"void k_dp_pass<(\d+), (\d+), (true|false), (true|false), (true|false)>", k)
+    m = re.match(r"void k_dp_pass<(\d+), (\d+), (true|false), (true|false), (true|false)(?:, (?:true|false))?>", k)
     if m:
         w, s, rev, exact, low = int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true", m.group(5) == "true"
         base = "dp_%s_%s" % ("byte" if w == 16 else "word", "rev" if rev else "fwd")
@@ -77,5 +77,26 @@ def main(kt, fd, wd, tag):
     print("wrote %s_pmc.md, pmc_latest.json (%d kernels)" % (tag, len(out)))
 
 
+SQ = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+      "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"]
+
+
+def sq_table(sd, tag, note):
+    """<tag>_sq_counters.md from a `--pmc SQ_*` pass (per launch that did real work)"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    cols = {c: load(sd, c) for c in SQ}
+    ks = sorted(cols["SQ_INSTS_VALU"], key=lambda k: -cols["SQ_INSTS_VALU"][k][1])
+    with open(os.path.join(here, "%s_sq_counters.md" % tag), "w") as o:
+        o.write("# %s: rocprofv3 --pmc SQ_* per launch (%s)\n\n" % (tag, note))
+        o.write("SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY count quad-cycles (MI355X_MICROARCH.md).\n\n")
+        o.write("| kernel | launches | " + " | ".join(c[3:] for c in SQ) + " |\n|---|---|" + "---|" * len(SQ) + "\n")
+        for k in ks[:14]:
+            n = cols["SQ_INSTS_VALU"][k][0]
+            o.write("| `%s` | %d | %s |\n" % (k[:60], n, " | ".join("%.3g" % (cols[c].get(k, [1, 0])[1] / max(1, cols[c].get(k, [1, 0])[0])) for c in SQ)))
+    print("wrote %s_sq_counters.md" % tag)
+
+
 if __name__ == "__main__":
     main(*sys.argv[1:5])
+    if len(sys.argv) > 5:
+        sq_table(sys.argv[5], sys.argv[4], sys.argv[6] if len(sys.argv) > 6 else "bench.py --steps 2 --warmup 1 --streams 1: one stream, so a launch = 1 M reads")
