@@ -30,6 +30,8 @@ READS_PER_GPU = 1_000_000
 READ_LEN, WINDOW_LEN = 150, 300
 SCORING = (3, 2, 3, 1)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_CLOCK_GHZ = 2.4             # peak engine clock; the DP kernels sustain ~2.3 (GRBM_GUI_ACTIVE / 8 / duration)
+PK16_CYCLES_PER_INST = 3.13      # v_pk_{add,sub,max}_i16, v_perm_b32, DPP moves at 4 waves/SIMD (profiles/r01_valu_issue_ubench.txt)
 # algorithmic HBM bytes per alignment: read codes + 8 B offsets in, 28 B fixed record
 # + 4 B per CIGAR op out; the shared window is amortised over the batch
 ALG_BYTES_FIXED = READ_LEN + 8 + 28
@@ -153,6 +155,21 @@ def main():
                 traffic = json.load(open(pmc)).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # VALU issue, the bound that actually binds this path: wave-instructions of the dominant
+        # kernel from the committed rocprofv3 SQ_INSTS_VALU pass, over its live duration, against the issue rate of
+        # packed 16-bit VALU measured by tools/ubench_valu.hip (1 wave-instruction per 3.13 cycles per SIMD)
+        valu = None
+        sq = os.path.join(ROOT, "profiles", "sq_latest.json")
+        if os.path.exists(sq):
+            try:
+                per_read = json.load(open(sq))["kernels"][dom.replace("dp_word_first", "dp_word_fwd")]["valu_insts_per_launch"] / 1e6
+                rate = per_read * per_launch / (dom_ms * 1e-3) / 1e9
+                ceil_ = 1024 * VALU_CLOCK_GHZ / PK16_CYCLES_PER_INST
+                valu = {"achieved": round(rate, 1), "peak": round(ceil_, 1), "unit": "G wave-instr/s", "frac": round(rate / ceil_, 4),
+                        "insts_per_alignment": round(per_read, 1),
+                        "note": "streams overlap, so per-launch durations are stretched; single-stream figure in DESIGN.md"}
+            except Exception:
+                valu = None
         out = {
             "metric": "million read-alignments/sec (150 bp x 300 bp, affine gap)",
             "value": round(value, 4), "unit": "million alignments/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -170,7 +187,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel": dom,
                          "kernel_ms_per_launch": round(dom_ms, 4),
                          "alg_bytes_per_launch": int(alg_bytes),
-                         "note": "integer-VALU-bound DP: HBM fraction is expected << 1 (SURVEY 8d)"},
+                         "note": "integer-VALU-bound DP: HBM fraction is expected << 1 (SURVEY 8d)", "valu_issue": valu},
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},   # summed over the streams (they overlap)
             "gpu_event_ms_per_step": round(aligners[0].last_run_ms(), 4),
             "mean_cigar_ops": round(mean_cigar, 3),

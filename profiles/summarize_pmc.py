@@ -93,7 +93,14 @@ def sq_table(sd, tag, note):
         for k in ks[:14]:
             n = cols["SQ_INSTS_VALU"][k][0]
             o.write("| `%s` | %d | %s |\n" % (k[:60], n, " | ".join("%.3g" % (cols[c].get(k, [1, 0])[1] / max(1, cols[c].get(k, [1, 0])[0])) for c in SQ)))
-    print("wrote %s_sq_counters.md" % tag)
+    # VALU wave-instructions per launch of each bench kernel class (single-stream pass: a launch = the whole batch)
+    out = {}
+    for k in ks:
+        n, v = cols["SQ_INSTS_VALU"][k]
+        e = out.setdefault(bench_name(k), {"valu_insts_per_launch": 0})
+        e["valu_insts_per_launch"] = max(e["valu_insts_per_launch"], int(v / max(1, n)))
+    json.dump({"note": note, "kernels": out}, open(os.path.join(here, "sq_latest.json"), "w"), indent=1, sort_keys=True)
+    print("wrote %s_sq_counters.md, sq_latest.json" % tag)
 
 
 if __name__ == "__main__":
