@@ -231,6 +231,11 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
     }
 }
 
+#if !defined(IPX_CPU_EMU) && !defined(IPX_NO_STRIPE_ASM)
+#define IPX_STRIPE_ASM 1
+#else
+#define IPX_STRIPE_ASM 0
+#endif
 // ------------------------------------------------------------------------------------------------
 // k_dp_pass: one striped Smith-Waterman pass over a tile of 128/W reads per wavefront
 //   W    = SSE lanes of the reference pass: 16 (8-bit semantics) or 8 (16-bit semantics)
@@ -271,6 +276,11 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
     constexpr int G = 64 / W;
     constexpr int NA = 2 * G;
     constexpr bool BYTE = (W == 16);
+    // the reference's step-by-step lazy-F loop is needed for reads with gap_open <= gap_ext and, in the exact
+    // 8-bit passes, for carries in signed-compare territory.  The selector-profile kernels of the 16-bit passes
+    // and of the lower-bound stage leave it out (the host launches them only when no job has gap_open <= gap_ext):
+    // without that loop the H registers of a column are defined once, in place, and no copies are needed.
+    constexpr bool STEP = !(PERM && (W == 8 || LOW));
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
     unsigned char *lds = IPX_LDS_BASE;
@@ -341,6 +351,10 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
 #else
         const pk16 fast_static = (gO[0] > gE[0] ? 0x0000FFFFu : 0u) | (gO[1] > gE[1] ? 0xFFFF0000u : 0u);
 #endif
+        if (!STEP) {                                            // this variant has no step loop: refuse what would need it
+            const bool bad = (job[0] >= 0 && gO[0] <= gE[0]) || (job[1] >= 0 && gO[1] <= gE[1]);
+            if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
+        }
         const pk16 bigthr = pk_make(127 + gE[0], 127 + gE[1]);  // F carry > 127+gapE: signed-byte compare territory
         pk16 D1, D2, D4, D8;                                    // decay of a carry across 1/2/4/8 whole segments
         {
@@ -502,8 +516,73 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
             }
             if (!PERM) {
                 IPX_DP_STRIPE(pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]))
-            } else {
+            } else if (!IPX_STRIPE_ASM || !EXACT) {
                 IPX_DP_STRIPE(pk_sext_hi8(pk_perm(tab1, tab0, SEL[PERM ? j : 0])))
+            } else {
+#if IPX_STRIPE_ASM
+                // The same recurrence, hand-scheduled (gfx950).  A packed 16-bit op that feeds the very next packed
+                // op costs a wait state, and the compiler's schedule left ~50 of them per column plus a copy of
+                // every H register (old H[j] is the next segment's diagonal, so old and new overlapped).  Here a
+                // segment's three dependent ops (H -> H-gapO -> F) are interleaved with the independent work of the
+                // next two segments (score lookup, diagonal add, E): no wait states, and H[j] is updated in
+                // place because the diagonal add of segment j+1 reads the old H[j] first.
+                //   hp = max(diag + score, E)   of the segment about to be finished     (prepared one block ahead)
+                //   em = E - gapE               of the same segment
+                //   p1 = score of the next segment                                       (prepared one block ahead)
+                if (SMAX > 0) {
+                    pk16 hp, em, p1 = 0, q, vFm, tt;
+                    {
+                        const pk16 p0 = pk_sext_hi8(pk_perm(tab1, tab0, SEL[0]));
+                        hp = pk_max(pk_add_sat(vH, p0), E[0]);
+                        em = pk_subus(E[0], ge);
+                        if (SMAX > 1) p1 = pk_sext_hi8(pk_perm(tab1, tab0, SEL[SMAX > 1 ? 1 : 0]));
+                    }
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) {
+                        if (j + 2 < SMAX) {
+                            asm volatile(
+                                "v_pk_add_i16 %7, %0, %6 clamp\n\t"            /* q  = H[j](old) + score[j+1]          */
+                                "v_pk_sub_u16 %8, %2, %15 clamp\n\t"           /* F' = F - gapE                         */
+                                "v_pk_max_i16 %0, %4, %2\n\t"                  /* H[j] = max(hp, F)                     */
+                                "v_perm_b32 %6, %13, %12, %11\n\t"             /* score[j+2] lookup ...                 */
+                                "v_pk_sub_u16 %9, %0, %14 clamp\n\t"           /* tt = H[j] - gapO                      */
+                                "v_pk_ashrrev_i16 %6, 8, %6 op_sel_hi:[0,1]\n\t" /* ... sign-extended                  */
+                                "v_pk_max_i16 %2, %8, %9\n\t"                  /* F = max(F', tt)                       */
+                                "v_pk_max_i16 %1, %5, %9\n\t"                  /* E[j] = max(E[j]-gapE, tt)             */
+                                "v_pk_max_i16 %3, %3, %0\n\t"                  /* column maximum                        */
+                                "v_pk_max_i16 %4, %7, %10\n\t"                 /* hp = max(q, E[j+1])                   */
+                                "v_pk_sub_u16 %5, %10, %15 clamp"               /* em = E[j+1] - gapE                    */
+                                : "+v"(H[j]), "+v"(E[j]), "+v"(vF), "+v"(cmx), "+v"(hp), "+v"(em), "+v"(p1), "=&v"(q), "=&v"(vFm), "=&v"(tt)
+                                : "v"(E[j + 1 < SMAX ? j + 1 : 0]), "v"(SEL[j + 2 < SMAX ? j + 2 : 0]), "v"(tab0), "v"(tab1), "v"(go), "v"(ge));
+                        } else if (j + 1 < SMAX) {
+                            asm volatile(
+                                "v_pk_add_i16 %7, %0, %6 clamp\n\t"
+                                "v_pk_sub_u16 %8, %2, %12 clamp\n\t"
+                                "v_pk_max_i16 %0, %4, %2\n\t"
+                                "v_pk_max_i16 %4, %7, %10\n\t"                 /* hp = max(q, E[j+1]) (fills the gap)   */
+                                "v_pk_sub_u16 %9, %0, %11 clamp\n\t"
+                                "v_pk_max_i16 %3, %3, %0\n\t"                  /* column maximum (fills the gap)        */
+                                "v_pk_max_i16 %2, %8, %9\n\t"
+                                "v_pk_max_i16 %1, %5, %9\n\t"
+                                "v_pk_sub_u16 %5, %10, %12 clamp"
+                                : "+v"(H[j]), "+v"(E[j]), "+v"(vF), "+v"(cmx), "+v"(hp), "+v"(em), "+v"(p1), "=&v"(q), "=&v"(vFm), "=&v"(tt)
+                                : "v"(E[j + 1 < SMAX ? j + 1 : 0]), "v"(go), "v"(ge));
+                        } else {
+                            asm volatile(
+                                "v_pk_sub_u16 %6, %2, %9 clamp\n\t"
+                                "v_pk_max_i16 %0, %4, %2\n\t"
+                                "s_nop 0\n\t"
+                                "v_pk_sub_u16 %7, %0, %8 clamp\n\t"
+                                "v_pk_max_i16 %3, %3, %0\n\t"
+                                "v_pk_max_i16 %2, %6, %7\n\t"
+                                "v_pk_max_i16 %1, %5, %7"
+                                : "+v"(H[j]), "+v"(E[j]), "+v"(vF), "+v"(cmx), "+v"(hp), "+v"(em), "=&v"(vFm), "=&v"(tt)
+                                : "v"(go), "v"(ge));
+                        }
+                    }
+                    Hlast = H[SA - 1];
+                }
+#endif
             }
 #undef IPX_DP_STRIPE
 
@@ -537,6 +616,39 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     if (W == 16) { y = xl_row_shr<8>(x); x = pk_max(x, pk_subus(y, D8)); }
                     cmx = pk_max(cmx, x);
                     pk16 a = x;
+                    if (PERM && EXACT && IPX_STRIPE_ASM) {
+#if IPX_STRIPE_ASM
+                        // H[j] = max(H[j], a), a -= gapE, hand-scheduled like the stripe: two alternating carry
+                        // registers keep every operand two instructions away from the op that produced it,
+                        // and H is updated in place
+                        pk16 a2;
+                        IPX_UNROLL
+                        for (int j = 0; j < SMAX; j += 4) {
+                            if (j + 3 < SMAX)
+                                asm volatile("v_pk_sub_u16 %5, %4, %6 clamp\n\tv_pk_max_i16 %0, %0, %4\n\t"
+                                             "v_pk_sub_u16 %4, %5, %6 clamp\n\tv_pk_max_i16 %1, %1, %5\n\t"
+                                             "v_pk_sub_u16 %5, %4, %6 clamp\n\tv_pk_max_i16 %2, %2, %4\n\t"
+                                             "v_pk_sub_u16 %4, %5, %6 clamp\n\tv_pk_max_i16 %3, %3, %5"
+                                             : "+v"(H[j]), "+v"(H[j + 1 < SMAX ? j + 1 : 0]), "+v"(H[j + 2 < SMAX ? j + 2 : 0]),
+                                               "+v"(H[j + 3 < SMAX ? j + 3 : 0]), "+v"(a), "=&v"(a2)
+                                             : "v"(ge));
+                            else if (j + 2 < SMAX)
+                                asm volatile("v_pk_sub_u16 %4, %3, %5 clamp\n\tv_pk_max_i16 %0, %0, %3\n\t"
+                                             "v_pk_sub_u16 %3, %4, %5 clamp\n\tv_pk_max_i16 %1, %1, %4\n\t"
+                                             "s_nop 0\n\tv_pk_max_i16 %2, %2, %3"
+                                             : "+v"(H[j]), "+v"(H[j + 1 < SMAX ? j + 1 : 0]), "+v"(H[j + 2 < SMAX ? j + 2 : 0]), "+v"(a), "=&v"(a2)
+                                             : "v"(ge));
+                            else if (j + 1 < SMAX)
+                                asm volatile("v_pk_sub_u16 %3, %2, %4 clamp\n\tv_pk_max_i16 %0, %0, %2\n\t"
+                                             "s_nop 0\n\tv_pk_max_i16 %1, %1, %3"
+                                             : "+v"(H[j]), "+v"(H[j + 1 < SMAX ? j + 1 : 0]), "+v"(a), "=&v"(a2)
+                                             : "v"(ge));
+                            else if (j < SMAX)
+                                asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(H[j]) : "v"(a));
+                        }
+                        Hlast = H[SA - 1];
+#endif
+                    } else {
                     IPX_UNROLL
                     for (int j = 0; j < SMAX; ++j) {
                         if (j < S) {
@@ -545,11 +657,12 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                             if (j == S - 1) Hlast = H[j];
                         }
                     }
+                    }
                 }
                 vF &= ~fe;
             }
             // step-by-step loop for the remaining reads, per-read exit
-            for (int k = 0; k < W; ++k) {
+            for (int k = 0; STEP && k < W; ++k) {
                 vF = xl_row_shr1(vF);
                 if (W == 8 && l == 0) vF = 0;
                 if (!xl_any(vF != 0)) break;

@@ -28,6 +28,7 @@ struct IpxDims {
     int max_ref_len;                   // longest window of the batch
     uint8_t has8[IPX_NUM_CLASSES];     // segLen classes present among the reads, 8-bit pass
     uint8_t has16[IPX_NUM_CLASSES];    // ... 16-bit pass
+    uint8_t any_slow_gap;              // some job has gap_open <= gap_ext
 };
 
 static inline void ipx_dims_add_read(IpxDims &d, int len)
@@ -95,7 +96,9 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
             be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, false>, be.dp_grid(), 64,          \
                       ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);         \
         break;
-    const bool perm = ipx_perm_profile_ok(b.mat);
+    // the selector-profile kernels of the 16-bit passes and of the 8-bit lower-bound stage have no stepped lazy-F
+    // loop (k_dp_pass, STEP): they are for batches in which every job has gap_open > gap_ext
+    const bool perm = ipx_perm_profile_ok(b.mat) && ((W == 16 && !LOW) || !b.any_slow_gap);
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
         IPX_DP_CASE(7) IPX_DP_CASE(8) IPX_DP_CASE(9) IPX_DP_CASE(10) IPX_DP_CASE(11) IPX_DP_CASE(12) IPX_DP_CASE(13)

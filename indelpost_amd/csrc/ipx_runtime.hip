@@ -229,6 +229,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         const int64_t len = read_off[i + 1] - read_off[i];
         if (len < 0 || len > 8 * IPX_MAX_SEG) { set_err("read %lld has length %lld (limit %d)", (long long)i, (long long)len, 8 * IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
         ipx_dims_add_read(d, (int)len);
+        if (gap_open[i] <= gap_ext[i]) d.any_slow_gap = 1;
         if (ref_id[i] < 0 || ref_id[i] >= n_refs) { set_err("job %lld: ref_id %d out of range", (long long)i, ref_id[i]); return IPX_ERR_ARG; }
     }
     c->n_jobs = n_jobs; c->n_refs = n_refs; c->dims = d; c->have_mask = mask_len != nullptr;
@@ -342,6 +343,7 @@ int ipx_run(ipx_ctx *c)
     b.word_first_len = getenv("IPX_NO_WORD_FIRST") ? 0 : ipx_word_first_len(c->mat, c->bias);
     b.byte_safe_len = getenv("IPX_NO_BYTE_SAFE") ? 0 : ipx_byte_safe_len(c->mat, c->bias);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
+    b.any_slow_gap = c->dims.any_slow_gap;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
     HipBackend be{c};
@@ -377,6 +379,7 @@ int ipx_sync(ipx_ctx *c)
     if (st & IPX_STATUS_REF_TOO_LONG) { set_err("a window is longer than %d", IPX_MAX_REFLEN); return IPX_ERR_REF_TOO_LONG; }
     if (st & IPX_STATUS_CIGAR_POOL) { set_err("device cigar pool exhausted (%u ops)", c->cigar_cap); return IPX_ERR_CIGAR_POOL; }
     if (st & IPX_STATUS_TB_SCRATCH) { set_err("traceback scratch exhausted"); return IPX_ERR_INTERNAL; }
+    if (st & IPX_STATUS_INTERNAL) { set_err("internal: a kernel variant met a job it was not built for"); return IPX_ERR_INTERNAL; }
     return IPX_OK;
 }
 

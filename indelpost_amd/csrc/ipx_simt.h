@@ -180,5 +180,10 @@ IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v);
 // ---- helpers shared by both builds -------------------------------------------------------------
 // per-half "non-zero -> 0xFFFF" mask
 IPX_DEV pk16 pk_nzmask(pk16 x) { return pk_sub(0u, pk_minu(x, 0x00010001u)); }
-IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
+#if defined(IPX_CPU_EMU)
+IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { return (a & mask) | (b & ~mask); }
+#else
+// one v_bfi_b32 (left to itself the compiler sometimes splits it into v_and + v_and_or)
+IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { pk16 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b)); return r; }
+#endif
 IPX_DEV pk16 pk_splat(int v) { return pk_make(v, v); }

@@ -68,6 +68,7 @@ struct IpxBatch {
                                 //   lower-bound stage of the 8-bit pass, whose only gain is a cheap overflow verdict; speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)
+    uint8_t any_slow_gap;       // some job has gap_open <= gap_ext (its lazy-F has to be stepped): chooses kernel variants
     uint16_t filters;
     int32_t filterd;
     IpxResult *res;             // n_jobs
@@ -93,4 +94,5 @@ enum {
     IPX_STATUS_READ_TOO_LONG = 2,
     IPX_STATUS_REF_TOO_LONG = 4,
     IPX_STATUS_TB_SCRATCH = 8,
+    IPX_STATUS_INTERNAL = 16,      // a kernel variant met a job it was not built for (host-side routing error)
 };

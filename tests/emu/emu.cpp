@@ -190,6 +190,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     }
     for (int64_t i = 0; i < n_jobs; ++i) {
         ipx_dims_add_read(d, (int)(read_off[i + 1] - read_off[i]));
+        if (gap_open[i] <= gap_ext[i]) d.any_slow_gap = 1;
     }
     int8_t *packed = zalloc<int8_t>((size_t)tot + 64);
     be.launch(IPX_KEY(IPX_K_PACK, 0), k_pack_refs, 2, 256, 0, refs, ref_off, (const int64_t *)refp_off.data(), packed, n_refs);
@@ -198,6 +199,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.n_jobs = n_jobs; b.n_refs = n_refs; b.reads = reads; b.read_off = read_off;
     b.refs_packed = packed; b.refp_off = refp_off.data(); b.ref_len = ref_len.data(); b.ref_id = ref_id;
     b.gap_open = gap_open; b.gap_ext = gap_ext; b.mask_len = mask_len;
+    b.any_slow_gap = d.any_slow_gap;
     memcpy(b.mat, mat, 25);
     int bias = 0;
     for (int k = 0; k < 25; ++k) if (mat[k] < bias) bias = mat[k];
