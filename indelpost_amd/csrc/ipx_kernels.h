@@ -303,6 +303,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
         int cls = cls_lo;
         while (tile >= p.tile_off[cls + 1]) ++cls;
         if (!EXACT && cls < 64 && ((skip_classes >> cls) & 1ull)) continue;   // class owned by an exact-segLen launch
+        if (!EXACT && cls > SMAX) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL); continue; }   // sweep kernel sized too small (host error)
         const int S = EXACT ? SMAX : (int)xl_first((uint32_t)cls);
         const uint32_t first = p.cls_off[cls] + (tile - p.tile_off[cls]) * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;

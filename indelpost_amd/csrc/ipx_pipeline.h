@@ -128,8 +128,21 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uin
     bool rest = false;                                            // anything the exact launches do not cover?
     for (int c = 0; c <= top; ++c)
         if ((REV || has[c]) && !(c < 64 && ((exact >> c) & 1ull))) rest = true;
-    if (rest)
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.dp_grid(), 64,
+    if (!rest) return;
+    // the sweep kernel keeps segLen registers for its largest class: size it for the largest class it
+    // really has to serve (reverse passes: usually only short prefixes are left over), because the 64-segment
+    // version needs a whole SIMD's register file per wave and queues behind everything else on a busy GPU
+    int need = 0;
+    for (int c = 0; c <= top; ++c)
+        if ((REV || has[c]) && !(c < 64 && ((exact >> c) & 1ull))) need = c;
+    if (REV && need <= 16)
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 16, REV, false, LOW>, be.sweep_grid(), 64,
+                  ipx_dp_lds_bytes(W, 16, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
+    else if (REV && need <= 32)
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 32, REV, false, LOW>, be.sweep_grid(), 64,
+                  ipx_dp_lds_bytes(W, 32, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
+    else
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.sweep_grid(), 64,
                   ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
 }
 

@@ -91,6 +91,13 @@ struct HipBackend {
         const int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
         return (int)(g < c->dp_grid_cap ? g : c->dp_grid_cap);
     }
+    // the sweep kernel usually finds only a few leftover tiles: a smaller grid (its blocks stride over all tiles
+    // anyway) spares thousands of block launches that would each wait for register space on a busy GPU
+    int sweep_grid() const
+    {
+        const int64_t g = dp_grid(), cap = (int64_t)c->num_cu * 8;
+        return (int)(g < cap ? g : cap);
+    }
     int flat_grid(int64_t n) const
     {
         int64_t g = (n + 255) / 256;

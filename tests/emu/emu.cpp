@@ -152,6 +152,7 @@ struct EmuBackend {
     int launches[IPX_NUM_KEYS];
     EmuBackend() { memset(launches, 0, sizeof launches); }
     int dp_grid() const { return 3; }
+    int sweep_grid() const { return 2; }
     int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
     template <class K, class... A>
