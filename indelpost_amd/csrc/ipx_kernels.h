@@ -204,18 +204,22 @@ IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
 }
 
 // one wave: exclusive scans over the 65 classes -> slot and tile offsets (NA = alignments per tile)
-IPX_KERNEL void k_plan_scan(IpxPlan p, int na)
+IPX_KERNEL void k_plan_scan(IpxPlan p, int na, int pass)
 {
     if (IPX_TID == 0) {
         uint32_t so = 0, to = 0;
+        uint32_t *st = p.stats ? p.stats + pass * (IPX_NUM_CLASSES + 1) : nullptr;
         for (int c = 0; c < IPX_NUM_CLASSES; ++c) {
             p.cls_off[c] = so;
             p.tile_off[c] = to;
             so += p.count[c];
-            to += (p.count[c] + (uint32_t)na - 1u) / (uint32_t)na;
+            const uint32_t t = (p.count[c] + (uint32_t)na - 1u) / (uint32_t)na;
+            to += t;
+            if (st) st[c] = t;
         }
         p.cls_off[IPX_NUM_CLASSES] = so;
         p.tile_off[IPX_NUM_CLASSES] = to;
+        if (st) st[IPX_NUM_CLASSES] = to;
     }
 }
 

@@ -89,11 +89,11 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
         if (perm)                                                                                            \
-            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, true>, be.dp_grid(), 64,           \
+            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, true>, be.dp_grid(pass, N), 64,           \
                       ipx_dp_lds_bytes(W, N, REV, maxcols, true), b, p, N, N, maxcols,                       \
                       pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true) ? IPX_PASS_MC_LDS : 0), (uint64_t)0);  \
         else                                                                                                 \
-            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, false>, be.dp_grid(), 64,          \
+            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, false>, be.dp_grid(pass, N), 64,          \
                       ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);         \
         break;
     // the selector-profile kernels of the 16-bit passes and of the 8-bit lower-bound stage have no stepped lazy-F
@@ -136,13 +136,13 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uin
     for (int c = 0; c <= top; ++c)
         if ((REV || has[c]) && !(c < 64 && ((exact >> c) & 1ull))) need = c;
     if (REV && need <= 16)
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 16, REV, false, LOW>, be.sweep_grid(), 64,
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 16, REV, false, LOW>, be.sweep_grid(pass, exact, top), 64,
                   ipx_dp_lds_bytes(W, 16, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
     else if (REV && need <= 32)
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 32, REV, false, LOW>, be.sweep_grid(), 64,
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 32, REV, false, LOW>, be.sweep_grid(pass, exact, top), 64,
                   ipx_dp_lds_bytes(W, 32, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
     else
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.sweep_grid(), 64,
+        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.sweep_grid(pass, exact, top), 64,
                   ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
 }
 
@@ -151,7 +151,7 @@ static void ipx_plan_pass(BE &be, const IpxBatch &b, const IpxPlan &p, int pass,
 {
     be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_zero, 1, 128, 0, p);
     be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.flat_grid(b.n_jobs), 256, 0, b, p, pass);
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scan, 1, 64, 0, p, na);
+    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scan, 1, 64, 0, p, na, pass);
     be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scatter, be.flat_grid(b.n_jobs), 256, 0, b, p, pass);
 }
 

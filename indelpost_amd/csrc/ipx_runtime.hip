@@ -79,6 +79,8 @@ struct ipx_ctx {
     hipEvent_t run_start = nullptr, run_stop = nullptr;
     float last_run_ms = 0.f;
     int64_t dp_grid_cap = 1;                    // DP blocks per launch (each owns a column-maxima scratch region)
+    uint32_t prev_tiles[IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1)] = {0};   // planner tile counts of the previous run, per pass and class
+    bool prev_valid = false;
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
 };
 
@@ -91,12 +93,27 @@ struct HipBackend {
         const int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
         return (int)(g < c->dp_grid_cap ? g : c->dp_grid_cap);
     }
-    // the sweep kernel usually finds only a few leftover tiles: a smaller grid (its blocks stride over all tiles
-    // anyway) spares thousands of block launches that would each wait for register space on a busy GPU
-    int sweep_grid() const
+    // Which passes a job takes is decided on the device, so the host does not know how many tiles a DP launch will
+    // find; many find none.  A block that finds nothing still has to be dispatched, and on a GPU busy with other
+    // streams' kernels it waits for register space first.  So launches are sized from the tile counts the planner
+    // saw in the PREVIOUS run of this context (read back in ipx_sync).  Any grid is correct (blocks stride over the
+    // tiles); a wrong guess only costs speed, and never less than 1/16 of the full grid is launched.
+    int sized(int64_t tiles) const
     {
-        const int64_t g = dp_grid(), cap = (int64_t)c->num_cu * 8;
-        return (int)(g < cap ? g : cap);
+        const int64_t full = dp_grid();
+        if (!c->prev_valid) return (int)full;
+        int64_t g = tiles + tiles / 4 + 8, lo = full / 16 > 0 ? full / 16 : 1;
+        if (g < lo) g = lo;
+        return (int)(g < full ? g : full);
+    }
+    int dp_grid(int pass, int cls) const { return sized(c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + cls]); }
+    int sweep_grid(int pass, uint64_t covered, int top) const
+    {
+        int64_t t = 0;
+        for (int k = 0; k <= top && k < IPX_NUM_CLASSES; ++k)
+            if (!(k < 64 && ((covered >> k) & 1ull))) t += c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + k];
+        const int64_t g = sized(t), cap = (int64_t)c->num_cu * 8;
+        return (int)(c->prev_valid ? g : (g < cap ? g : cap));
     }
     int flat_grid(int64_t n) const
     {
@@ -317,6 +334,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.plan.cls_off = sm; sm += 128;
     c->ws.plan.tile_off = sm; sm += 128;
     c->ws.plan.max_cols = nullptr;
+    c->ws.plan.stats = sm; sm += IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1);
     c->ws.plan.perm = c->perm.as<uint32_t>();
     c->ws.tb_list = c->tb_list.as<uint32_t>();
     c->ws.tb_esc = c->tb_esc.as<uint32_t>();
@@ -382,6 +400,10 @@ int ipx_sync(ipx_ctx *c)
     if (c->n_jobs == 0) return IPX_OK;
     uint32_t st = 0;
     HIPCHK(hipMemcpy(&st, c->batch.status, 4, hipMemcpyDeviceToHost));
+    if (c->ws.plan.stats && !getenv("IPX_NO_ADAPTIVE_GRID")) {
+        HIPCHK(hipMemcpy(c->prev_tiles, c->ws.plan.stats, sizeof c->prev_tiles, hipMemcpyDeviceToHost));
+        c->prev_valid = true;
+    }
     if (st & IPX_STATUS_READ_TOO_LONG) { set_err("a read needs more than %d striped segments", IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
     if (st & IPX_STATUS_REF_TOO_LONG) { set_err("a window is longer than %d", IPX_MAX_REFLEN); return IPX_ERR_REF_TOO_LONG; }
     if (st & IPX_STATUS_CIGAR_POOL) { set_err("device cigar pool exhausted (%u ops)", c->cigar_cap); return IPX_ERR_CIGAR_POOL; }

@@ -87,6 +87,8 @@ struct IpxPlan {
     uint32_t *tile_off;   // [IPX_NUM_CLASSES+1] first tile of class
     uint32_t *perm;       // [n_jobs] job ids grouped by class
     uint32_t *max_cols;   // [IPX_NUM_CLASSES] longest column count in the class (sizes the LDS stage)
+    uint32_t *stats;      // [IPX_NUM_PASSES][IPX_NUM_CLASSES+1] tiles per class of the last plan of each pass (last entry: all
+                          //   classes); read back by the host after a run to size the next run's launches (speed only)
 };
 
 enum {

@@ -152,7 +152,8 @@ struct EmuBackend {
     int launches[IPX_NUM_KEYS];
     EmuBackend() { memset(launches, 0, sizeof launches); }
     int dp_grid() const { return 3; }
-    int sweep_grid() const { return 2; }
+    int dp_grid(int, int) const { return 3; }
+    int sweep_grid(int, uint64_t, int) const { return 2; }
     int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
     template <class K, class... A>
@@ -219,6 +220,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.plan.tile_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
     ws.plan.perm = zalloc<uint32_t>((size_t)n_jobs);
     ws.plan.max_cols = nullptr;
+    ws.plan.stats = nullptr;
     ws.tb_list = zalloc<uint32_t>(7 * (size_t)n_jobs);
     ws.tb_esc = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc_n = nullptr;
