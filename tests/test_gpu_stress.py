@@ -11,7 +11,7 @@ from indelpost_amd.batch import JobTable
 pytestmark = pytest.mark.gpu
 
 
-def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True):
+def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True, fast_gaps_only=False):
     refs = []
     for k in range(n_refs):
         alpha = 2 if (alpha_mix and k % 4 == 0) else 4
@@ -22,6 +22,8 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True):
     reads, rid, go, ge = [], [], [], []
     gaps = [(3, 1), (3, 0), (5, 1), (5, 0), (4, 1), (4, 0), (1, 1), (1, 0), (0, 0), (0, 1), (1, 2), (2, 2), (6, 3),
             (10, 1), (2, 1), (255, 1)]
+    if fast_gaps_only:          # gap_open > gap_ext everywhere: the batch takes the kernels that have no stepped lazy-F loop
+        gaps = [g for g in gaps if g[0] > g[1]]
     for i in range(n_jobs):
         k = int(rng.integers(0, n_refs))
         w = refs[k]
@@ -46,7 +48,11 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True):
             r[rng.integers(0, L, max(1, L // 10))] = 4
         g = gaps[int(rng.integers(0, len(gaps)))]
         reads.append(r); rid.append(k)
-        go.append(L if i % 17 == 0 else g[0]); ge.append(g[1])
+        if i % 17 == 0:         # indelPost's mutant-contig jobs: gap_open = len(read) (narrowed to uint8 like the reference does)
+            go.append(min(max(L, g[1] + 1), 255) if fast_gaps_only else L)
+        else:
+            go.append(g[0])
+        ge.append(g[1])
     return JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
 
 
@@ -54,14 +60,17 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True):
 # 8-bit stage for every read, 8-bit pass before the 16-bit one, LDS-staged profile): same results required
 @pytest.mark.parametrize("scoring,knobs", [((3, 2), ()), ((1, 1), ()), ((2, 2), ()), ((1, 3), ()), ((5, 4), ()), ((2, 4), ()),
                                            ((1, 1), ("IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE")),
-                                           ((3, 2), ("IPX_NO_WORD_FIRST", "IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE"))])
+                                           ((3, 2), ("IPX_NO_WORD_FIRST", "IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE")),
+                                           ((3, 2), ("fast_gaps",)), ((2, 2), ("fast_gaps",)), ((1, 1), ("fast_gaps",))])
 def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd, monkeypatch):
     from oracle.oracle import cpu_batch_results, fnv1a_ops
+    fast = "fast_gaps" in knobs
     for k in knobs:
-        monkeypatch.setenv(k, "1")
-    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs))
+        if k.startswith("IPX_"):
+            monkeypatch.setenv(k, "1")
+    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs) + (5000 if fast else 0))
     n = int(os.environ.get("IPX_STRESS_JOBS", "30000"))
-    jobs = _make_jobs(rng, n, 97)
+    jobs = _make_jobs(rng, n, 97, fast_gaps_only=fast)
     be = oracle_mod.Backend("reference" if oracle_mod.have_reference() else "port")
     mat = oracle_mod.dna_matrix(*scoring)
     cores = len(os.sched_getaffinity(0))
