@@ -134,6 +134,12 @@ int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches);   /* arrays of ipx_n
 float ipx_last_run_ms(ipx_ctx *c);            /* events around the last ipx_run, valid after ipx_sync */
 int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out9);   /* traceback routing of the last run (diagnostic) */
 
+/* host-side helper: the CIGAR strings of a whole batch in one call, formatted as sswpy.pyx:283-289 does per
+ * alignment ("%d%c" per op, op letters MIDNSHP=X, anything above 8 -> 'M').  Strings are concatenated into `out`
+ * (no terminators); off[i]..off[i+1] delimits job i (empty for a job without CIGAR), off has n+1 entries.
+ * Returns the total length, or -(needed length) when `cap` is too small (nothing is written then). */
+int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, char *out, int64_t cap, int64_t *off);
+
 /* deterministic synthetic workload of SURVEY.md section 8d (xorshift64), host side:
  * one window of `wl` codes and n reads of `rl` codes; returns the final generator state */
 uint64_t ipx_synth_window(uint64_t state, int8_t *ref, int32_t wl);

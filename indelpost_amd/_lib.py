@@ -32,7 +32,7 @@ EXPORTS = [
     "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_upload",
     "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch", "ipx_set_profiling",
     "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_last_run_ms", "ipx_debug_tb_counts",
-    "ipx_synth_window", "ipx_synth_reads",
+    "ipx_synth_window", "ipx_synth_reads", "ipx_format_cigars",
 ]
 
 
@@ -100,6 +100,8 @@ def lib():
     L.ipx_debug_tb_counts.restype = C.c_int
     L.ipx_synth_window.restype = C.c_uint64
     L.ipx_synth_window.argtypes = [C.c_uint64, vp, i32]
+    L.ipx_format_cigars.restype = C.c_int64
+    L.ipx_format_cigars.argtypes = [vp, vp, i64, vp, i64, vp]
     L.ipx_synth_reads.restype = C.c_uint64
     L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
     for f in ("ipx_set_params", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch",

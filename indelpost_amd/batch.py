@@ -123,6 +123,27 @@ class BatchResult:
         ops = self.cigar_ops(i)
         return None if ops is None else cigar_to_string(ops)
 
+    def cigar_strings(self):
+        """All CIGAR strings of the batch (None where the reference returns no cigar), formatted by the
+        library in one call (sswpy.pyx:283-289) instead of one Python loop per alignment."""
+        from . import _lib
+        n = len(self.records)
+        if n == 0:
+            return []
+        L = _lib.lib()
+        rec = np.ascontiguousarray(self.records)
+        pool = np.ascontiguousarray(self.cigar_pool, np.uint32)
+        off = np.zeros(n + 1, np.int64)
+        cap = 12 * int(rec["cigar_len"].astype(np.int64).sum()) + 16
+        buf = np.zeros(cap, np.uint8)
+        tot = L.ipx_format_cigars(rec.ctypes.data, pool.ctypes.data if pool.size else None, n, buf.ctypes.data, cap, off.ctypes.data)
+        if tot < 0:
+            raise RuntimeError("ipx_format_cigars: buffer too small")
+        text = buf[:tot].tobytes().decode("ascii")
+        o = off.tolist()
+        has = (rec["cigar_len"] > 0).tolist()
+        return [text[o[i]:o[i + 1]] if has[i] else None for i in range(n)]
+
     def as_dict(self, i):
         """Same keys as oracle.Backend.align() for direct comparison in tests."""
         r = self.records[i]

@@ -502,6 +502,39 @@ uint64_t ipx_synth_window(uint64_t state, int8_t *ref, int32_t wl)
     for (int32_t i = 0; i < wl; ++i) ref[i] = (int8_t)(xs_next(state) & 3);
     return state;
 }
+int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, char *out, int64_t cap, int64_t *off)
+{
+    static const char ops[] = "MIDNSHP=X";
+    if (!rec || !off || n < 0) return 0;
+    int64_t need = 0;                                     // pass 1: exact size
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t *c = cigar_pool + rec[i].cigar_off;
+        for (int k = 0; k < rec[i].cigar_len; ++k) {
+            uint32_t len = c[k] >> 4;
+            int d = 1;
+            while (len >= 10) { len /= 10; ++d; }
+            need += d + 1;
+        }
+    }
+    if (need > cap || (!out && need > 0)) return -need;
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        off[i] = w;
+        const uint32_t *c = cigar_pool + rec[i].cigar_off;
+        for (int k = 0; k < rec[i].cigar_len; ++k) {
+            char tmp[12];
+            uint32_t len = c[k] >> 4;
+            int d = 0;
+            do { tmp[d++] = (char)('0' + len % 10); len /= 10; } while (len);
+            while (d) out[w++] = tmp[--d];
+            const uint32_t op = c[k] & 15u;
+            out[w++] = op > 8 ? 'M' : ops[op];
+        }
+    }
+    off[n] = w;
+    return w;
+}
+
 uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *reads, int64_t n, int32_t rl)
 {
     for (int64_t k = 0; k < n; ++k) {

@@ -12,7 +12,7 @@ the returned Alignment tuples and is not part of this path.
 import numpy as np
 
 from .batch import JobTable, encode_dna
-from .sswpy import SSW, _alignment_from, _gpu
+from .sswpy import SSW, _alignment_from, _gpu, alignments_from
 
 
 def make_aligner(ref_seq, match_score, mismatch_penalty):
@@ -32,17 +32,20 @@ def realign_pileup_jobs(read_seqs, mut_ref, ref_ref, gap_open_penalty, gap_exten
     """Job table of the two alignments per read that is_target_by_ssw issues (localn.pyx:253-255):
     job 2k   = read k vs the reference contig, (gap_open, gap_ext);
     job 2k+1 = read k vs the mutant contig, gap_open = len(read) (forced ungapped), gap_ext."""
-    reads, rid, go, ge = [], [], [], []
-    for s in read_seqs:
-        e = encode_dna(s.encode("utf8") if isinstance(s, str) else s)
-        reads += [e, e]
-        rid += [0, 1]
-        go += [gap_open_penalty, len(s)]
-        ge += [gap_extension_penalty, gap_extension_penalty]
+    n = len(read_seqs)
+    raw = [s.encode("utf8") if isinstance(s, str) else bytes(s) for s in read_seqs]
+    lens = np.fromiter((len(b) for b in raw), np.int64, n)
+    # every read twice, back to back (job 2k, 2k+1); one table lookup for the whole pileup
+    reads = encode_dna(b"".join([b for b in raw for _ in (0, 1)]))
+    read_off = np.zeros(2 * n + 1, np.int64)
+    np.cumsum(np.repeat(lens, 2), out=read_off[1:])
+    rid = np.tile(np.array([0, 1], np.int32), n)
+    go = np.empty(2 * n, np.int64); go[0::2] = gap_open_penalty; go[1::2] = lens
+    ge = np.full(2 * n, gap_extension_penalty, np.int64)
     refs = [encode_dna(ref_ref.encode("utf8") if isinstance(ref_ref, str) else ref_ref),
             encode_dna(mut_ref.encode("utf8") if isinstance(mut_ref, str) else mut_ref)]
-    return JobTable.from_sequences(reads, refs, np.asarray(rid, np.int32), np.asarray(go, np.int64),
-                                   np.asarray(ge, np.int64), encoded=True)
+    ref_off = np.array([0, len(refs[0]), len(refs[0]) + len(refs[1])], np.int64)
+    return JobTable(reads, read_off, np.concatenate(refs), ref_off, rid, go, ge)
 
 
 def align_pileup(read_seqs, mut_ref, ref_ref, match_score, mismatch_penalty, gap_open_penalty,
@@ -59,4 +62,5 @@ def align_pileup(read_seqs, mut_ref, ref_ref, match_score, mismatch_penalty, gap
     from .batch import dna_score_matrix
     g.set_scoring(matrix=dna_score_matrix(match_score, mismatch_penalty), flag=1, score_size=2)
     res = g.align(jobs)
-    return [(_alignment_from(res, 2 * k), _alignment_from(res, 2 * k + 1)) for k in range(len(read_seqs))]
+    alns = alignments_from(res)
+    return list(zip(alns[0::2], alns[1::2]))

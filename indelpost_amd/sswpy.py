@@ -52,6 +52,16 @@ def _alignment_from(res, i):
                      int(r["ref_end1"]), int(r["read_begin1"]), int(r["read_end1"]))
 
 
+def alignments_from(res):
+    """All Alignment tuples of a batch at once (same content as _alignment_from(res, i) for every i): the
+    record columns are converted with one numpy call each and the CIGAR strings by the library."""
+    rec = res.records
+    if len(rec) and bool((rec["mode"] == 2).any()):     # reference: ssw_align returned NULL (sswpy.pyx:220-223)
+        raise ValueError("Problem Running alignment, see stdout")
+    cols = [res.cigar_strings()] + [rec[f].tolist() for f in ("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1")]
+    return list(map(Alignment._make, zip(*cols)))
+
+
 class SSW:
     """Mirror of ``cdef class SSW`` (sswpy.pyx:99-337)."""
 
@@ -116,7 +126,7 @@ class SSW:
         if not enc:
             return []
         res = self._run(enc, gap_open, gap_extension, window)
-        return [_alignment_from(res, i) for i in range(len(enc))]
+        return alignments_from(res)
 
 
 def force_align(read: STR_T, reference: STR_T, force_overhang: bool = False, aligner: SSW = None) -> Alignment:

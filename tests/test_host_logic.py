@@ -60,6 +60,25 @@ def test_make_aligner_align_and_batch(emu_as_gpu):
         assert ma == ip.align(mut_al, r, len(r), 1)           # localn.pyx:253-255
 
 
+def test_vectorised_host_paths_equal_the_per_item_ones(emu):
+    """cigar_strings() / alignments_from() / realign_pileup_jobs() do in bulk what the per-alignment code does"""
+    from indelpost_amd import localn, sswpy
+    from indelpost_amd.batch import encode_dna
+    ref = "ACGTTGCATGCCGATAGGCTTAACGGATCGATCGGGATTACAGCTAGCTAG"
+    mut = ref[:20] + ref[26:]
+    reads = ["GCATGCCGATAGGCTTAACGG", b"GATCGATCGGATTACAGC", "TTTTTTTT", "NNNNN", "A", "gcatgccgataggcttaacgg" * 3]
+    jobs = localn.realign_pileup_jobs(reads, mut, ref, 3, 1)
+    enc = [encode_dna(r) for r in reads]
+    slow = JobTable.from_sequences([e for e in enc for _ in (0, 1)], [encode_dna(ref), encode_dna(mut)], [0, 1] * len(reads),
+                                   [v for e in enc for v in (3, len(e))], 1, encoded=True)
+    for f in ("reads", "read_off", "refs", "ref_off", "ref_id", "gap_open", "gap_ext"):
+        assert np.array_equal(getattr(jobs, f), getattr(slow, f)), f
+    res = emu(0, 3, 2).align(jobs)
+    assert res.cigar_strings() == [res.cigar_string(i) for i in range(len(res))]
+    assert sswpy.alignments_from(res) == [sswpy._alignment_from(res, i) for i in range(len(res))]
+    assert localn.realign_pileup_jobs([], mut, ref, 3, 1).n_jobs == 0
+
+
 def test_gap_penalties_narrow_to_uint8():
     j = JobTable.from_sequences(["ACGT"], ["ACGT"], [0], 300, 256 + 7)
     assert j.gap_open[0] == 300 - 256 and j.gap_ext[0] == 7  # ssw.h:129-130
