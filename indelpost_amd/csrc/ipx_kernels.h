@@ -989,9 +989,11 @@ template <> struct IpxTbWord<5> { typedef uint64_t type; };
 template <> struct IpxTbWord<6> { typedef uint64_t type; };
 template <> struct IpxTbWord<7> { typedef uint64_t type; };
 
+// (body shared by the per-width kernels and the all-widths kernel below: `bid` of `gdim` blocks work on this list,
+//  `scratch_bid` names the block's direction-word region)
 template <int BW>
-IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
-                               unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n)
+IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_t *list_n, int rowcap,
+                          unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n, int bid, int gdim, int scratch_bid)
 {
     constexpr int WD = 2 * BW + 1, W = 2 * BW + 3;
     typedef typename IpxTbWord<BW>::type word_t;
@@ -999,12 +1001,12 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
     unsigned char *lds = IPX_LDS_BASE;
     int8_t *matl = (int8_t *)lds;
     uint32_t *cig = (uint32_t *)(lds + 64) + lane;                      // [k*64]
-    word_t *dirw = (word_t *)(dir_scratch + (size_t)IPX_BID * ipx_tbf_scratch_bytes_per_block(rowcap)) + lane;   // [row*64]
+    word_t *dirw = (word_t *)(dir_scratch + (size_t)scratch_bid * ipx_tbf_scratch_bytes_per_block(rowcap)) + lane;   // [row*64]
     if (lane < 25) matl[lane] = b.mat[lane];
     IPX_SYNC();
     const uint32_t n = *list_n;
 
-    for (int64_t base = (int64_t)IPX_BID * 64; base < (int64_t)n; base += (int64_t)IPX_GDIM * 64) {
+    for (int64_t base = (int64_t)bid * 64; base < (int64_t)n; base += (int64_t)gdim * 64) {
         const int64_t li = base + lane;
         if (li >= (int64_t)n) continue;
         const int64_t jb = list[li];
@@ -1146,6 +1148,32 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
         r.cigar_off = off;
         r.cigar_len = (uint16_t)lcnt;
         b.res[jb] = r;
+    }
+}
+
+template <int BW>
+IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
+                               unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n)
+{
+    tb_fast_body<BW>(b, list, list_n, rowcap, dir_scratch, next, next_n, (int)IPX_BID, (int)IPX_GDIM, (int)IPX_BID);
+}
+
+// All seven widths in ONE launch, `per` blocks each (block b serves width b / per + 1).  For small batches: the seven
+// per-width launches are each a chain of dependent steps one lane deep, so run one after the other they are most
+// of the latency of a small call (1000 jobs: 1.85 of 3.0 ms); side by side they cost as much as the slowest.
+IPX_KERNEL_WAVE void k_tb_fast_all(IpxBatch b, const uint32_t *lists, const uint32_t *counters, int rowcap,
+                                   unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n, int per)
+{
+    const int bid = (int)IPX_BID, bw = bid / per, loc = bid % per;
+    const uint32_t *list = lists + (int64_t)bw * b.n_jobs, *cnt = counters + bw;
+    switch (bw) {
+    case 0: tb_fast_body<1>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 1: tb_fast_body<2>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 2: tb_fast_body<3>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 3: tb_fast_body<4>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 4: tb_fast_body<5>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 5: tb_fast_body<6>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    default: tb_fast_body<7>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
     }
 }
 

@@ -204,8 +204,18 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
               BW <= 3 ? ws.tbf_waves : (ws.tbf_waves + 7) / 8, 64, ipx_tbf_lds_bytes(), b,   /* wide first bands are rare */ \
               (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
               rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n);
+            // small batch: all widths side by side in one launch (latency); large batch: one launch per width
+            // (each width has its own register footprint and occupancy)
+            const int64_t fuse_max = getenv("IPX_TBF_FUSE_MAX") ? atoll(getenv("IPX_TBF_FUSE_MAX")) : 20000;
+            const int per_want = (int)((b.n_jobs + 63) / 64) + 1, per_have = ws.tbf_waves / 7;
+            if (b.n_jobs <= fuse_max && per_have >= 1) {
+                const int per = per_want < per_have ? per_want : per_have;
+                be.launch(IPX_KEY(IPX_K_TRACEBACK, 9), k_tb_fast_all, 7 * per, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
+                          (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per);
+            } else {
             IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)
             IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
+            }
 #undef IPX_TBF_LAUNCH
             // everything else: one wavefront per job
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_tb_coop, ws.tb1_waves, 64, ipx_tbc_lds_bytes(ws.tb1.arrcap), b,

@@ -468,7 +468,7 @@ const char *ipx_kernel_class_name(int k)
     if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X || kc == IPX_K_WORD_FIRST) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
-    } else if (kc == IPX_K_TRACEBACK) { if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
+    } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
     else snprintf(buf, sizeof buf, "%s", k_names[kc]);
     return buf;
 }

@@ -227,9 +227,9 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.tb_list_n = zalloc<uint32_t>(8);
     ws.tb_esc_n = ws.tb_list_n + 7;
     const IpxTbSizing s1 = ipx_tb1_sizing(d);
-    ws.tbf_waves = 2;
-    ws.tbf_scratch = (unsigned char *)malloc(ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 2 + 64);
-    memset(ws.tbf_scratch, 0x5A, ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 2);
+    ws.tbf_waves = 7;
+    ws.tbf_scratch = (unsigned char *)malloc(ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 7 + 64);
+    memset(ws.tbf_scratch, 0x5A, ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 7);
     ws.tb1_waves = 2;
     memset(&ws.tb1, 0, sizeof ws.tb1);
     ws.tb1.arrcap = s1.arrcap; ws.tb1.dircap = s1.dircap; ws.tb1.cigcap = s1.cigcap;

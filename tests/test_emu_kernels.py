@@ -153,13 +153,13 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
         assert res.as_dict(i) == port.align(reads[i], w, mat, 3, 1, mask_len=masks[i]), i
 
 
-@pytest.mark.parametrize("knobs", [("IPX_NO_BYTE_SAFE",), ("IPX_NO_PERM_PROFILE",),
+@pytest.mark.parametrize("knobs", [("IPX_NO_BYTE_SAFE",), ("IPX_NO_PERM_PROFILE", "IPX_TBF_FUSE_MAX"),
                                    ("IPX_NO_WORD_FIRST", "IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE")])
 def test_emu_routing_knobs_off(emu, golden_c, monkeypatch, knobs):
     """The speed-only routing decisions (skip the lower-bound stage for reads that cannot overflow, 16-bit
     pass first, register-selector profile) must not change any result: golden vectors with each turned off."""
     for k in knobs:
-        monkeypatch.setenv(k, "1")
+        monkeypatch.setenv(k, "0" if k == "IPX_TBF_FUSE_MAX" else "1")     # FUSE_MAX=0: one traceback launch per band width
     groups = {}
     for c in golden_c[160:320]:
         groups.setdefault((c["match"], c["mismatch"]), []).append(c)
