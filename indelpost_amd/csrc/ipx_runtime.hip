@@ -300,6 +300,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     int wf = (int)((n_jobs + 63) / 64);
     if (wf < 1) wf = 1;
     if (wf > c->num_cu * 16) wf = c->num_cu * 16;
+    if (wf < 7 * ((int)((n_jobs + 63) / 64) + 1) && n_jobs <= 65536)        // room for the all-widths launch of small batches
+        wf = 7 * ((int)((n_jobs + 63) / 64) + 1);
     c->ws.tbf_waves = wf;
     {
         const int want = d.max_read_len > 0 ? d.max_read_len : 1;
