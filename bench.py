@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams (independent slices of the batch) per GPU")
+    ap.add_argument("--all-kernel-times", action="store_true", help="HIP events around every launch, not only the DP kernels (costs ~1.5 %%)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,7 +117,8 @@ def main():
         step()
     barrier()
     for g in aligners:
-        g.set_profiling(True)                # HIP events around every kernel launch, on the ctx stream
+        # HIP events on the ctx streams: around the striped DP kernels only (level 2) unless --all-kernel-times
+        g.set_profiling(0 if os.environ.get("IPX_BENCH_NO_PROFILE") else (1 if args.all_kernel_times else 2))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

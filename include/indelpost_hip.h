@@ -127,7 +127,7 @@ int ipx_align_batch(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, co
                     ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops);
 
 /* measurement: HIP events on the context's stream */
-int ipx_set_profiling(ipx_ctx *c, int on);
+int ipx_set_profiling(ipx_ctx *c, int on);   /* 0 off, 1 every kernel launch, 2 only the striped DP kernels */
 int ipx_num_kernel_classes(void);
 const char *ipx_kernel_class_name(int k);
 int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches);   /* arrays of ipx_num_kernel_classes() */

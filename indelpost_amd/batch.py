@@ -252,7 +252,8 @@ class GpuAligner:
 
     # -- measurement --
     def set_profiling(self, on):
-        self._check(self._L.ipx_set_profiling(self._ctx, 1 if on else 0), "ipx_set_profiling")
+        # on: False/0 off, True/1 events around every launch, 2 only around the striped DP kernels
+        self._check(self._L.ipx_set_profiling(self._ctx, int(on)), "ipx_set_profiling")
 
     def kernel_times(self):
         k = self._L.ipx_num_kernel_classes()
