@@ -262,6 +262,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         if (gap_open[i] <= gap_ext[i]) d.any_slow_gap = 1;
         if (ref_id[i] < 0 || ref_id[i] >= n_refs) { set_err("job %lld: ref_id %d out of range", (long long)i, ref_id[i]); return IPX_ERR_ARG; }
     }
+    // launch sizes learned from the previous run only carry over to a batch of similar size
+    if (c->prev_valid && (n_jobs > 2 * c->n_jobs || 2 * n_jobs < c->n_jobs)) c->prev_valid = false;
     c->n_jobs = n_jobs; c->n_refs = n_refs; c->dims = d; c->have_mask = mask_len != nullptr;
 
     if (c->reads.ensure((size_t)read_bytes + 64) || c->read_off.ensure(8 * ((size_t)n_jobs + 1)) ||
@@ -315,7 +317,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         if (c->tbf.ensure(ipx_tbf_scratch_bytes_per_block(rowcap) * (size_t)wf + 64)) return IPX_ERR_NO_DEVICE;
         c->ws.tbf_scratch = c->tbf.as<unsigned char>();
     }
-    int w1 = c->num_cu * 8;                                  // one job per block in k_tb_coop (latency-bound: many blocks)
+    static const int tb1_mult = getenv("IPX_TB1_MULT") ? atoi(getenv("IPX_TB1_MULT")) : 16;
+    int w1 = c->num_cu * (tb1_mult > 0 ? tb1_mult : 16);      // one job per block in k_tb_coop (latency-bound: many blocks)
     const size_t lim1 = 1024ull << 20;
     while (w1 > 1 && ipx_tbc_bytes_per_block(s1) * (size_t)w1 > lim1) w1 /= 2;
     c->ws.tb1_waves = w1;
