@@ -516,7 +516,6 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     E[j] = pk_max(e, tt);                                                                    \
                     vF = pk_subus(vF, ge);                                                                   \
                     vF = pk_max(vF, tt);                                                                     \
-                    if (PERM) IPX_SCHED_FENCE();                                                             \
                 }                                                                                            \
             }
             if (!PERM) {

@@ -24,7 +24,6 @@ struct uint2 { uint32_t x, y; };
 #define IPX_DEV static inline
 #define IPX_HD static inline
 #define IPX_UNROLL
-#define IPX_SCHED_FENCE() ((void)0)
 #define IPX_VMEM_FENCE() ((void)0)
 #define IPX_COMPILER_FENCE() ((void)0)
 #define IPX_NOUNROLL
@@ -113,8 +112,6 @@ IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 #define IPX_DEV __device__ __forceinline__
 #define IPX_HD __host__ __device__ inline
 #define IPX_UNROLL _Pragma("unroll")
-// keep the instruction scheduler from moving anything across this point (register pressure control)
-#define IPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // wait for every outstanding global-memory operation here, and keep later ones below this point
 #define IPX_VMEM_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define IPX_NOUNROLL _Pragma("unroll 1")
