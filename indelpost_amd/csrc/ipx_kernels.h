@@ -192,6 +192,24 @@ IPX_DEV uint32_t wave_class_slot(uint32_t *counter, int cls)
     return slot;
 }
 
+// Block-level version: the waves of a block first add up in LDS (one LDS atomic per class per wave), then ONE thread
+// per class adds the block's total to the global counter and publishes the base -- 8x fewer same-address global
+// atomics with 512-thread blocks.  All threads of the block must call it (barriers).  lds: 160 uint32.
+IPX_DEV uint32_t block_class_slot(uint32_t *counter, int cls, uint32_t *lds)
+{
+    uint32_t *cnt = lds, *base = lds + 80;
+    const int tid = IPX_TID;
+    if (tid < 80) cnt[tid] = 0;
+    IPX_SYNC();
+    const uint32_t local = wave_class_slot(cnt, cls);
+    IPX_SYNC();
+    if (tid < 80 && cnt[tid] != 0) base[tid] = atomic_add_u32(&counter[tid], cnt[tid]);
+    IPX_SYNC();
+    return cls >= 0 ? base[cls] + local : 0u;
+}
+#define IPX_PLAN_BLOCK 512
+#define IPX_PLAN_LDS 640
+
 IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
 {
     const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
@@ -199,7 +217,7 @@ IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
     for (int64_t q = 0; q < rounds; ++q) {                 // every lane runs every round (wave-wide ballots)
         const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
         const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
-        (void)wave_class_slot(p.count, cls);
+        (void)block_class_slot(p.count, cls, (uint32_t *)IPX_LDS_BASE);
     }
 }
 
@@ -230,7 +248,7 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
     for (int64_t q = 0; q < rounds; ++q) {
         const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
         const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
-        const uint32_t pos = wave_class_slot(p.cursor, cls);
+        const uint32_t pos = block_class_slot(p.cursor, cls, (uint32_t *)IPX_LDS_BASE);
         if (cls >= 0) p.perm[p.cls_off[cls] + pos] = (uint32_t)i;
     }
 }
@@ -958,7 +976,7 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                 cls = bw <= IPX_TBF_MAXBW ? bw - 1 : IPX_TBF_MAXBW;
             }
         }
-        const uint32_t slot = wave_class_slot(counters, cls);
+        const uint32_t slot = block_class_slot(counters, cls, (uint32_t *)IPX_LDS_BASE);
         if (cls >= 0) {
             if (cls < IPX_TBF_MAXBW) lists[(int64_t)cls * b.n_jobs + slot] = (uint32_t)i;
             else esc[slot] = (uint32_t)i;
