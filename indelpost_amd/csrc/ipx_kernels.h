@@ -4,7 +4,9 @@
 //   k_dp_pass      <- sw_sse2_byte ssw.c:197-384 and sw_sse2_word ssw.c:410-586, forward and reverse,
 //                     including qP_byte/qP_word profile construction (ssw.c:163-188, 386-408) and
 //                     seq_reverse (ssw.c:774-785)
-//   k_traceback    <- banded_sw ssw.c:588-772
+//   k_tb_fast<BW>, k_tb_coop <- banded_sw ssw.c:588-772 (lane per job for first bands 1..7, wave per job otherwise)
+//   k_prove_overflow : nothing in the reference -- proves, from a lower bound, that the 8-bit pass (which the
+//                     reference always runs first, ssw.c:842-847) overflows, so that it need not be run
 //   k_plan_* / k_tb_list : the control flow of ssw_align (ssw.c:842-916), turned into device-side
 //                     job lists so that a whole batch runs without a host round trip
 //
@@ -19,16 +21,19 @@
 //     8-bit pass at the first column that reaches 255-bias (ssw.c:327) no value ever saturates
 //     before that column, so the un-saturated 16-bit result is bit-identical up to the exit.
 //   * the striped column state (H, E, and the column saved at the best score) lives in registers:
-//     segment j of the reference = register j, fully unrolled.
-//   * the substitution profile of the tile's reads is staged in LDS as int8 [letter][j][lane][half]
-//     (12 KB per wave at 150 bp): per column each lane fetches its two profile bytes per segment,
-//     bank-conflict free by construction.  Keeping the per-wave LDS footprint small matters more than
-//     wide reads here: a wave issues one instruction per ~4 cycles, so a SIMD needs >= 2-3 resident
-//     waves (8-12 per CU) to approach its issue rate.  For the same reason the per-column maxima go
-//     to a small per-block global scratch (L2-resident) instead of LDS.  The window bytes are
-//     streamed four columns at a time from 4-byte aligned, re-packed windows.
-//   * lazy-F keeps the reference's data-dependent exit per read: a read that would `goto end`
-//     gets its F zeroed, the wave leaves the loop when every read is out.
+//     segment j of the reference = register j, fully unrolled (one instantiation per segLen 0..32).
+//   * the substitution profile: each striped row keeps a v_perm_b32 selector of its two read letters in
+//     a register and a column's scores are looked up in an 8-byte table of the two window letters
+//     (PERM; needs mat[.][N] == 0); otherwise an int8 profile [letter][j][lane][half] staged in LDS
+//     (12 KB per wave at 150 bp).  Window letters are streamed four columns per dword from 4-byte
+//     aligned, re-packed windows; per-column maxima stay in LDS when the window is short enough.
+//   * the kernels are bound by VALU issue (packed 16-bit ops issue every ~3.1-4.3 cycles per SIMD
+//     depending on the resident waves), not by latency or memory: what counts is instructions per
+//     cell and wait states between dependent packed ops -- hence the hand-scheduled stripe.
+//   * lazy-F: a max-plus prefix scan over the lanes where that provably equals the reference's loop
+//     (gap_open > gap_ext, no carry in signed-compare territory); otherwise the reference's
+//     step-by-step loop with its data-dependent exit per read (a read that would `goto end` gets its
+//     F zeroed, the wave leaves the loop when every read is out).
 #pragma once
 #include "ipx_simt.h"
 #include "ipx_types.h"
