@@ -1000,7 +1000,7 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
 // the job's own letters and the CIGAR.  Cells keep the reference's linear index width_d*i + (j-shift),
 // so out-of-band reads alias exactly as in the reference.  Jobs that need a second band iteration
 // (max < score, ssw.c:669), more rows than `rowcap` or more than 32 CIGAR runs go to `next`.
-// Dynamic LDS: 64 B matrix | 32*64 CIGAR ops.   Global: rowcap*64 direction words (4 or 8 bytes) per block
+// Dynamic LDS: 64 B score table (per read letter, 5 window letters) | 32*64 CIGAR ops.   Global: rowcap*64 direction words (4 or 8 bytes) per block
 // ------------------------------------------------------------------------------------------------
 #define IPX_TBF_CIG 32
 static inline int ipx_tbf_lds_bytes() { return 64 + IPX_TBF_CIG * 256; }
@@ -1021,10 +1021,14 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
     typedef typename IpxTbWord<BW>::type word_t;
     const int lane = lane_id();
     unsigned char *lds = IPX_LDS_BASE;
-    int8_t *matl = (int8_t *)lds;
+    uint64_t *coltab = (uint64_t *)lds;                                 // [read letter a] -> bytes mat[c*5 + a], c = 0..4
     uint32_t *cig = (uint32_t *)(lds + 64) + lane;                      // [k*64]
     word_t *dirw = (word_t *)(dir_scratch + (size_t)scratch_bid * ipx_tbf_scratch_bytes_per_block(rowcap)) + lane;   // [row*64]
-    if (lane < 25) matl[lane] = b.mat[lane];
+    if (lane < 5) {
+        uint64_t t = 0;
+        for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
+        coltab[lane] = t;
+    }
     IPX_SYNC();
     const uint32_t n = *list_n;
 
@@ -1081,7 +1085,8 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
                 }
                 rc_next = i + 1 < readLen ? readp[i + 1] : 0;
                 c_next = ref_at(i + 1 + BW);
-                const int8_t *mrow = matl + rc;                         // mat[ref*5 + read]
+                const uint64_t mrow = coltab[rc];                       // this row's scores against the 5 window letters: one LDS
+                                                                        // read per row, the cells then only shift (mat[ref*5 + read])
                 int f = 0, hleft = 0;
                 word_t word = 0;
                 IPX_UNROLL
@@ -1103,7 +1108,7 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
                     const int f1 = fv > 0 ? fv : 0;
                     t1 = e1 > f1 ? e1 : f1;
                     const int rcode = (int)(((s2 < 8 ? win0 >> (8 * s2) : win1 >> (8 * (s2 - 8)))) & 0xFFu);
-                    t2 = hbd + mrow[rcode * 5];
+                    t2 = hbd + (int)(int8_t)(mrow >> (8 * rcode));
                     const int hv = t1 > t2 ? t1 : t2;
                     const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
                     if (act) {
