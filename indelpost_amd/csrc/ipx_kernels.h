@@ -212,7 +212,11 @@ IPX_DEV uint32_t block_class_slot(uint32_t *counter, int cls, uint32_t *lds)
     IPX_SYNC();
     return cls >= 0 ? base[cls] + local : 0u;
 }
+#if defined(IPX_CPU_EMU)
+#define IPX_PLAN_BLOCK 128          // (two waves: enough to exercise the block-level path, cheaper to emulate)
+#else
 #define IPX_PLAN_BLOCK 512
+#endif
 #define IPX_PLAN_LDS 640
 
 IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
@@ -254,6 +258,9 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
         const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
         const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
         const uint32_t pos = block_class_slot(p.cursor, cls, (uint32_t *)IPX_LDS_BASE);
+#if defined(IPX_CPU_EMU)
+        if (cls >= 0 && (int64_t)(p.cls_off[cls] + pos) >= b.n_jobs) { fprintf(stderr, "emu: scatter out of range: pass %d job %lld cls %d off %u pos %u count %u\n", pass, (long long)i, cls, p.cls_off[cls], pos, p.count[cls]); abort(); }
+#endif
         if (cls >= 0) p.perm[p.cls_off[cls] + pos] = (uint32_t)i;
     }
 }

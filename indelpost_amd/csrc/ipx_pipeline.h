@@ -150,9 +150,9 @@ template <class BE>
 static void ipx_plan_pass(BE &be, const IpxBatch &b, const IpxPlan &p, int pass, int na)
 {
     be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_zero, 1, 128, 0, p);
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.flat_grid(b.n_jobs) / 2 + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass);
+    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.flat_grid(b.n_jobs) * 256 / IPX_PLAN_BLOCK + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass);
     be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scan, 1, 64, 0, p, na, pass);
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scatter, be.flat_grid(b.n_jobs) / 2 + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass);
+    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scatter, be.flat_grid(b.n_jobs) * 256 / IPX_PLAN_BLOCK + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass);
 }
 
 template <class BE>
@@ -195,7 +195,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             ipx_launch_dp<BE, 8, true, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
-            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs) / 2 + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
+            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs) * 256 / IPX_PLAN_BLOCK + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
             const int want = d.max_read_len > 0 ? d.max_read_len : 1;
             const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;

@@ -72,12 +72,21 @@ static void check_convergent(int me, const char *what)
         }
 }
 
+// Block-wide barrier: waves may reach it after different numbers of cross-lane operations (e.g. a loop over the
+// distinct classes of a wave), so a fiber waits here until every fiber of the block that is still running has
+// arrived -- one scheduler round is not enough.
+// Everybody then leaves in the NEXT scheduler round, in lane order, so the lock-step phase the lane exchanges
+// rely on (a lane is at most one operation behind the lanes before it) is restored.
+static long g_bar_gen = 0, g_round = 0, g_bar_open_round = -1;
+static int g_bar_count = 0;
+
 void block_barrier()
 {
-    const int me = g_cur;
-    ++g_epoch[me];
-    yield_to_sched();
-    check_convergent(me, "barrier");
+    const long gen = g_bar_gen;
+    int alive = 0;
+    for (const Fiber &f : g_fibers) alive += f.done ? 0 : 1;
+    if (++g_bar_count >= alive) { g_bar_count = 0; ++g_bar_gen; g_bar_open_round = g_round; }   // last arrival opens the barrier
+    while (g_bar_gen == gen || g_round <= g_bar_open_round) yield_to_sched();
 }
 
 uint32_t exchange(uint32_t v, int src_tid)
@@ -117,6 +126,8 @@ static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::fun
     g_slot[1].assign((size_t)bdim, 0);
     g_parity.assign((size_t)bdim, 0);
     g_epoch.assign((size_t)bdim, 0);
+    g_bar_count = 0;
+    g_bar_open_round = -1;
     g_body = body;
     for (int t = 0; t < bdim; ++t) {
         Fiber &f = g_fibers[t];
@@ -132,6 +143,7 @@ static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::fun
     }
     for (;;) {
         bool any = false;
+        ++g_round;
         for (int t = 0; t < bdim; ++t) {
             if (g_fibers[t].done) continue;
             any = true;
@@ -160,6 +172,7 @@ struct EmuBackend {
     void launch(int kclass, K kern, int grid, int block, int lds, A... args)
     {
         ++launches[kclass];
+        if (getenv("IPX_EMU_TRACE")) fprintf(stderr, "emu launch key %d grid %d block %d lds %d\n", kclass, grid, block, lds);
         std::function<void()> body = [=]() { kern(args...); };
         for (int bidx = 0; bidx < grid; ++bidx) ipx_emu::run_block(bidx, grid, block, lds, body);
     }
