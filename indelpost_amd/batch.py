@@ -91,6 +91,11 @@ class JobTable:
     def shard(self, lo, hi):
         """Contiguous job range [lo, hi) with only the windows it references."""
         rid = self.ref_id[lo:hi]
+        base = self.read_off[lo]
+        if len(self.refs) <= (1 << 20):       # few / small windows: ship them all, no renumbering (views, no copies)
+            return JobTable(self.reads[base:self.read_off[hi]], self.read_off[lo:hi + 1] - base, self.refs, self.ref_off,
+                            rid, self.gap_open[lo:hi], self.gap_ext[lo:hi],
+                            None if self.mask_len is None else self.mask_len[lo:hi])
         used, inv = np.unique(rid, return_inverse=True)
         lens = (self.ref_off[used + 1] - self.ref_off[used]) if len(used) else np.zeros(0, np.int64)
         fo = np.zeros(len(used) + 1, np.int64)
@@ -208,12 +213,22 @@ class GpuAligner:
     def sync(self):
         self._check(self._L.ipx_sync(self._ctx), "ipx_sync")
 
+    def download_into(self, rec, pool):
+        """Download into caller-owned buffers (contiguous views are fine).  Returns the number of CIGAR ops written,
+        or -(needed) when `pool` is too small (nothing usable was written then)."""
+        used = C.c_int64(0)
+        rc = self._L.ipx_download(self._ctx, C.c_void_p(rec.ctypes.data), C.c_void_p(pool.ctypes.data), len(pool), C.byref(used))
+        if rc == -5 and used.value > len(pool):
+            return -int(used.value)
+        self._check(rc, "ipx_download")
+        return int(used.value)
+
     def download(self, cigar_ops_per_job=16):
         n = self._n_jobs
         rec = np.zeros(n, RESULT_DTYPE)
         cap = max(1024, n * cigar_ops_per_job)
         while True:
-            pool = np.zeros(cap, np.uint32)
+            pool = np.empty(cap, np.uint32)
             used = C.c_int64(0)
             rc = self._L.ipx_download(self._ctx, _p(rec), _p(pool), cap, C.byref(used))
             if rc == -5 and used.value > cap:      # IPX_ERR_CIGAR_POOL: host pool too small
@@ -317,11 +332,33 @@ class MultiStreamAligner:
             p.sync()
 
     def download(self, cigar_ops_per_job=16):
-        return merge_results([p.download(cigar_ops_per_job) for p in self._active])
+        """Gather the slices' results.  Every slice downloads straight into its range of ONE record array and its own
+        region of ONE cigar pool (offsets rebased in place), so nothing is concatenated; the pool may have unused gaps
+        between the regions."""
+        if not hasattr(self._active[0], "download_into"):          # test back-ends
+            return merge_results([p.download(cigar_ops_per_job) for p in self._active])
+        ns = [p._n_jobs for p in self._active]
+        caps = [max(1024, n * cigar_ops_per_job) for n in ns]
+        rec = np.empty(sum(ns), RESULT_DTYPE)
+        pool = np.empty(sum(caps), np.uint32)
+        lo = pb = 0
+        for p, n, cap in zip(self._active, ns, caps):
+            used = p.download_into(rec[lo:lo + n], pool[pb:pb + cap])
+            if used < 0:                                           # a slice has more CIGAR ops than guessed: generic path
+                return merge_results([q.download(cigar_ops_per_job) for q in self._active])
+            rec["cigar_off"][lo:lo + n] += np.uint32(pb)
+            lo += n
+            pb += cap
+        return BatchResult(rec, pool)
 
     def align(self, jobs):
-        self.upload(jobs)
-        self.run()
+        k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
+        b = shard_bounds(jobs.n_jobs, k)
+        self._active = self.parts[:k]
+        self._slices = [jobs.shard(b[i], b[i + 1]) for i in range(k)]
+        for p, j in zip(self._active, self._slices):               # slice i computes while slice i+1 is still uploading
+            p.upload(j)
+            p.run()
         try:
             self.sync()
         except IpxError:
