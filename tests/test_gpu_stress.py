@@ -68,7 +68,8 @@ def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd, monke
     for k in knobs:
         if k.startswith("IPX_"):
             monkeypatch.setenv(k, "1")
-    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs) + (5000 if fast else 0))
+    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs) + (5000 if fast else 0)
+                                + 100000 * int(os.environ.get("IPX_STRESS_SEED", "0")))
     n = int(os.environ.get("IPX_STRESS_JOBS", "30000"))
     jobs = _make_jobs(rng, n, 97, fast_gaps_only=fast)
     be = oracle_mod.Backend("reference" if oracle_mod.have_reference() else "port")
