@@ -131,6 +131,9 @@ int ipx_set_profiling(ipx_ctx *c, int on);   /* 0 off, 1 every kernel launch, 2 
 int ipx_num_kernel_classes(void);
 const char *ipx_kernel_class_name(int k);
 int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches);   /* arrays of ipx_num_kernel_classes() */
+/* alignments processed by the launches of each striped-DP kernel class since profiling was switched on (planner tile
+ * counts x alignments per tile; 0 for the other classes): the "units one launch processes" of the roofline */
+int ipx_kernel_units(ipx_ctx *c, int64_t *units);
 float ipx_last_run_ms(ipx_ctx *c);            /* events around the last ipx_run, valid after ipx_sync */
 int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out9);   /* traceback routing of the last run (diagnostic) */
 
@@ -144,6 +147,12 @@ int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int
  * one window of `wl` codes and n reads of `rl` codes; returns the final generator state */
 uint64_t ipx_synth_window(uint64_t state, int8_t *ref, int32_t wl);
 uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *reads, int64_t n, int32_t rl);
+/* the same generator over many windows: n_windows windows with lengths drawn from
+ * [wl_lo, wl_hi]; per window `per` reads of each length in rls[0..n_rls) (clamped to the window length).  Caller
+ * buffers sized for the worst case; returns the number of jobs, -1 on a bad argument; *state is advanced. */
+int64_t ipx_synth_mixed(uint64_t *state, int32_t n_windows, int32_t wl_lo, int32_t wl_hi, const int32_t *rls,
+                        int32_t n_rls, int32_t per, int8_t *refs, int64_t *ref_off, int8_t *reads,
+                        int64_t *read_off, int32_t *ref_id);
 
 #ifdef __cplusplus
 }

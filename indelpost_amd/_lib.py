@@ -31,8 +31,8 @@ EXPORTS = [
     # batched interface
     "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_upload",
     "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch", "ipx_set_profiling",
-    "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_last_run_ms", "ipx_debug_tb_counts",
-    "ipx_synth_window", "ipx_synth_reads", "ipx_format_cigars",
+    "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts",
+    "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
     L.ipx_kernel_class_name.restype = C.c_char_p
     L.ipx_kernel_class_name.argtypes = [C.c_int]
     L.ipx_kernel_times.argtypes = [vp, vp, vp]
+    L.ipx_kernel_units.argtypes = [vp, vp]
+    L.ipx_kernel_units.restype = C.c_int
     L.ipx_last_run_ms.restype = C.c_float
     L.ipx_last_run_ms.argtypes = [vp]
     L.ipx_debug_tb_counts.argtypes = [vp, vp]
@@ -104,6 +106,8 @@ def lib():
     L.ipx_format_cigars.argtypes = [vp, vp, i64, vp, i64, vp]
     L.ipx_synth_reads.restype = C.c_uint64
     L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
+    L.ipx_synth_mixed.restype = i64
+    L.ipx_synth_mixed.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
     for f in ("ipx_set_params", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch",
               "ipx_set_profiling", "ipx_kernel_times"):
         getattr(L, f).restype = C.c_int

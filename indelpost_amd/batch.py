@@ -96,16 +96,42 @@ class JobTable:
             return JobTable(self.reads[base:self.read_off[hi]], self.read_off[lo:hi + 1] - base, self.refs, self.ref_off,
                             rid, self.gap_open[lo:hi], self.gap_ext[lo:hi],
                             None if self.mask_len is None else self.mask_len[lo:hi])
-        used, inv = np.unique(rid, return_inverse=True)
-        lens = (self.ref_off[used + 1] - self.ref_off[used]) if len(used) else np.zeros(0, np.int64)
+        mask = None if self.mask_len is None else self.mask_len[lo:hi]
+        reads, read_off = self.reads[base:self.read_off[hi]], self.read_off[lo:hi + 1] - base
+        if len(rid) == 0:
+            return JobTable(reads, read_off, np.zeros(0, np.int8), np.zeros(1, np.int64), rid, self.gap_open[lo:hi],
+                            self.gap_ext[lo:hi], mask)
+        r0, r1 = int(rid.min()), int(rid.max())
+        span = int(self.ref_off[r1 + 1] - self.ref_off[r0])
+        if span <= 2 * int(self.read_off[hi] - base) + (1 << 20):
+            # the shard's windows form a (nearly) dense id range, as in a table sorted by locus: ship that range as it
+            # lies (views), renumbering is one subtraction
+            return JobTable(reads, read_off, self.refs[self.ref_off[r0]:self.ref_off[r1 + 1]],
+                            self.ref_off[r0:r1 + 2] - self.ref_off[r0], rid - np.int32(r0), self.gap_open[lo:hi],
+                            self.gap_ext[lo:hi], mask)
+        used, inv = np.unique(rid, return_inverse=True)          # scattered windows: gather them with one fancy index
+        starts = self.ref_off[used]
+        lens = self.ref_off[used + 1] - starts
         fo = np.zeros(len(used) + 1, np.int64)
-        fo[1:] = np.cumsum(lens)
-        refs = (np.concatenate([self.refs[self.ref_off[u]:self.ref_off[u + 1]] for u in used])
-                if len(used) and fo[-1] else np.zeros(0, np.int8))
-        base = self.read_off[lo]
-        return JobTable(self.reads[base:self.read_off[hi]], self.read_off[lo:hi + 1] - base, refs, fo,
-                        inv.astype(np.int32), self.gap_open[lo:hi], self.gap_ext[lo:hi],
-                        None if self.mask_len is None else self.mask_len[lo:hi])
+        np.cumsum(lens, out=fo[1:])
+        idx = np.repeat(starts - fo[:-1], lens) + np.arange(int(fo[-1]), dtype=np.int64)
+        return JobTable(reads, read_off, self.refs[idx], fo, inv.astype(np.int32), self.gap_open[lo:hi],
+                        self.gap_ext[lo:hi], mask)
+
+
+def record_digest(rec, wsum):
+    """Order-sensitive 64-bit digest of a batch's results: every field of every record plus, per job, the weighted
+    sum of its BAM-encoded CIGAR ops  wsum[i] = sum_q cigar[q]*(q+1) mod 2^32.  bench.py compares it with the digest
+    of the reference's results on the same job table (tests/golden/bench_digests.json)."""
+    n = len(rec)
+    u = lambda a: np.asarray(a).astype(np.int64).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        mix = (u(rec["score1"]) + np.uint64(3) * u(rec["score2"]) + np.uint64(5) * u(rec["ref_begin1"].astype(np.int64) + 2)
+               + np.uint64(7) * u(rec["ref_end1"].astype(np.int64) + 2) + np.uint64(11) * u(rec["read_begin1"].astype(np.int64) + 2)
+               + np.uint64(13) * u(rec["read_end1"].astype(np.int64) + 2) + np.uint64(17) * u(rec["ref_end2"].astype(np.int64) + 2)
+               + np.uint64(19) * u(rec["flag"]) + np.uint64(23) * u(rec["cigar_len"]) + np.uint64(31) * u(wsum))
+        w = np.arange(1, n + 1, dtype=np.uint64)
+        return int((mix * w).sum(dtype=np.uint64))
 
 
 class BatchResult:
@@ -148,6 +174,24 @@ class BatchResult:
         o = off.tolist()
         has = (rec["cigar_len"] > 0).tolist()
         return [text[o[i]:o[i + 1]] if has[i] else None for i in range(n)]
+
+    def cigar_wsums(self):
+        """Per job: sum_q cigar[q]*(q+1) mod 2^32 (0 without a CIGAR), vectorised over the pool."""
+        rec = self.records
+        n = len(rec)
+        cl = rec["cigar_len"].astype(np.int64)
+        tot = int(cl.sum())
+        if tot == 0:
+            return np.zeros(n, np.uint32)
+        idx = np.repeat(np.arange(n), cl)
+        within = np.arange(tot) - np.repeat(np.cumsum(cl) - cl, cl)
+        ops = self.cigar_pool.astype(np.int64)[np.repeat(rec["cigar_off"].astype(np.int64), cl) + within]
+        # ops < 2^32 and within < 2^16: products and per-job sums stay far below 2^53, exact in float64
+        return (np.bincount(idx, weights=(ops * (within + 1)).astype(np.float64), minlength=n).astype(np.uint64)
+                & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+    def digest(self):
+        return record_digest(self.records, self.cigar_wsums())
 
     def as_dict(self, i):
         """Same keys as oracle.Backend.align() for direct comparison in tests."""
@@ -283,6 +327,17 @@ class GpuAligner:
                 out[name] = (t + float(ms[i]), c + int(cnt[i]))
         return out
 
+    def kernel_units(self):
+        """{kernel class name: alignments its launches processed since set_profiling} (striped DP kernels only)."""
+        k = self._L.ipx_num_kernel_classes()
+        un = np.zeros(k, np.int64)
+        self._check(self._L.ipx_kernel_units(self._ctx, _p(un)), "ipx_kernel_units")
+        out = {}
+        for i in np.flatnonzero(un):
+            name = self._L.ipx_kernel_class_name(int(i)).decode()
+            out[name] = out.get(name, 0) + int(un[i])
+        return out
+
     def traceback_routing(self):
         """jobs per first band width 1..7, jobs handed to the general kernel, jobs handed to the wide-band kernel"""
         out = np.zeros(9, np.uint32)
@@ -375,6 +430,13 @@ class MultiStreamAligner:
             for name, (t, c) in p.kernel_times().items():
                 t0, c0 = out.get(name, (0.0, 0))
                 out[name] = (t0 + t, c0 + c)
+        return out
+
+    def kernel_units(self):
+        out = {}
+        for p in self._active:
+            for name, u in p.kernel_units().items():
+                out[name] = out.get(name, 0) + u
         return out
 
     def last_run_ms(self):

@@ -99,6 +99,7 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
     // the selector-profile kernels of the 16-bit passes and of the 8-bit lower-bound stage have no stepped lazy-F
     // loop (k_dp_pass, STEP): they are for batches in which every job has gap_open > gap_ext
     const bool perm = ipx_perm_profile_ok(b.mat) && ((W == 16 && !LOW) || !b.any_slow_gap);
+    be.note_dp(IPX_KEY(kclass, S), pass, S, 128 / W);
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
         IPX_DP_CASE(7) IPX_DP_CASE(8) IPX_DP_CASE(9) IPX_DP_CASE(10) IPX_DP_CASE(11) IPX_DP_CASE(12) IPX_DP_CASE(13)

@@ -77,6 +77,8 @@ struct ipx_ctx {
     size_t ev_next = 0;
     float k_ms[IPX_NUM_KEYS];
     int k_launches[IPX_NUM_KEYS];
+    int64_t k_units[IPX_NUM_KEYS];              // alignments the launches of a DP timing key processed (planner tile counts x tile size)
+    int32_t k_dp_src[IPX_NUM_KEYS];             // DP timing key -> (pass * 128 + class) * 32 + alignments per tile, or -1
     hipEvent_t run_start = nullptr, run_stop = nullptr;
     float last_run_ms = 0.f;
     int64_t dp_grid_cap = 1;                    // DP blocks per launch (each owns a column-maxima scratch region)
@@ -123,6 +125,7 @@ struct HipBackend {
         const int64_t cap = (int64_t)c->num_cu * 8;
         return (int)(g < cap ? g : cap);
     }
+    void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 128 + cls) * 32 + na; }
     void zero_u32(uint32_t *p, int n)
     {
         hipError_t e = hipMemsetAsync(p, 0, sizeof(uint32_t) * (size_t)n, c->stream);
@@ -195,6 +198,8 @@ ipx_ctx *ipx_create(int device)
     (void)hipEventCreate(&c->run_stop);
     memset(c->k_ms, 0, sizeof c->k_ms);
     memset(c->k_launches, 0, sizeof c->k_launches);
+    memset(c->k_units, 0, sizeof c->k_units);
+    memset(c->k_dp_src, 0xFF, sizeof c->k_dp_src);
     // default scoring: SSW() class defaults, match 2 / mismatch 2 (sswpy.pyx:112)
     static const int8_t dflt[25] = {2, -2, -2, -2, 0, -2, 2, -2, -2, 0, -2, -2, 2, -2, 0, -2, -2, -2, 2, 0, 0, 0, 0, 0, 0};
     memcpy(c->mat, dflt, 25);
@@ -414,6 +419,12 @@ int ipx_sync(ipx_ctx *c)
     if (c->ws.plan.stats && !getenv("IPX_NO_ADAPTIVE_GRID")) {
         HIPCHK(hipMemcpy(c->prev_tiles, c->ws.plan.stats, sizeof c->prev_tiles, hipMemcpyDeviceToHost));
         c->prev_valid = true;
+        if (c->profiling)
+            for (int k = 0; k < IPX_NUM_KEYS; ++k)
+                if (c->k_dp_src[k] >= 0) {
+                    const int na = c->k_dp_src[k] & 31, pc = c->k_dp_src[k] >> 5;
+                    c->k_units[k] += (int64_t)c->prev_tiles[(pc >> 7) * (IPX_NUM_CLASSES + 1) + (pc & 127)] * na;
+                }
     }
     if (st & IPX_STATUS_READ_TOO_LONG) { set_err("a read needs more than %d striped segments", IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
     if (st & IPX_STATUS_REF_TOO_LONG) { set_err("a window is longer than %d", IPX_MAX_REFLEN); return IPX_ERR_REF_TOO_LONG; }
@@ -468,6 +479,7 @@ int ipx_set_profiling(ipx_ctx *c, int on)
     c->profiling_level = on >= 2 ? 2 : 1;
     memset(c->k_ms, 0, sizeof c->k_ms);
     memset(c->k_launches, 0, sizeof c->k_launches);
+    memset(c->k_units, 0, sizeof c->k_units);
     return IPX_OK;
 }
 int ipx_num_kernel_classes(void) { return IPX_NUM_KEYS; }
@@ -488,6 +500,12 @@ int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches)
 {
     if (!c) return IPX_ERR_ARG;
     for (int k = 0; k < IPX_NUM_KEYS; ++k) { if (ms) ms[k] = c->k_ms[k]; if (launches) launches[k] = c->k_launches[k]; }
+    return IPX_OK;
+}
+int ipx_kernel_units(ipx_ctx *c, int64_t *units)
+{
+    if (!c || !units) return IPX_ERR_ARG;
+    for (int k = 0; k < IPX_NUM_KEYS; ++k) units[k] = c->k_units[k];
     return IPX_OK;
 }
 float ipx_last_run_ms(ipx_ctx *c) { return c ? c->last_run_ms : 0.f; }
@@ -562,6 +580,32 @@ uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *
         }
     }
     return state;
+}
+
+// Multi-window form of the same generator: `n_windows` windows whose length is
+// drawn from [wl_lo, wl_hi], and for each window `per` reads of every length in rls[] (clamped to the window).
+// Buffers are caller-owned and sized for the worst case (n_windows*wl_hi codes, n_windows*per*sum(rls) codes,
+// n_windows*per*n_rls jobs); returns the number of jobs written.  state is updated in place.
+int64_t ipx_synth_mixed(uint64_t *state, int32_t n_windows, int32_t wl_lo, int32_t wl_hi, const int32_t *rls, int32_t n_rls,
+                        int32_t per, int8_t *refs, int64_t *ref_off, int8_t *reads, int64_t *read_off, int32_t *ref_id)
+{
+    if (!state || n_windows < 0 || wl_lo < 1 || wl_hi < wl_lo || n_rls < 0 || per < 0) return -1;
+    uint64_t st = *state;
+    int64_t job = 0, rpos = 0, fpos = 0;
+    ref_off[0] = 0; read_off[0] = 0;
+    for (int32_t w = 0; w < n_windows; ++w) {
+        const int32_t wl = wl_lo + (int32_t)(xs_next(st) % (uint32_t)(wl_hi - wl_lo + 1));
+        st = ipx_synth_window(st, refs + fpos, wl);
+        for (int32_t k = 0; k < n_rls; ++k) {
+            const int32_t rl = rls[k] < wl ? rls[k] : wl;
+            st = ipx_synth_reads(st, refs + fpos, wl, reads + rpos, per, rl);
+            for (int32_t q = 0; q < per; ++q) { rpos += rl; read_off[++job] = rpos; ref_id[job - 1] = w; }
+        }
+        fpos += wl;
+        ref_off[w + 1] = fpos;
+    }
+    *state = st;
+    return job;
 }
 
 // ---- the reference's four-call interface, executed on GPU 0 ---------------------------------------

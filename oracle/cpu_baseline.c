@@ -11,6 +11,7 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,12 +39,25 @@ typedef struct {
     const int8_t *mat;
     int64_t lo, hi;
     int64_t checksum, cigar_ops;
+    int cpu;                 /* logical CPU this thread pins itself to, or -1 */
 } work_t;
+
+/* one pinned thread per physical core.  The caller (bench.py) picks the logical CPUs. */
+static void pin_self(int cpu)
+{
+    if (cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   /* best effort: a refused mask leaves the thread unpinned */
+    }
+}
 
 static void *worker(void *arg)
 {
     work_t *w = (work_t *)arg;
     int64_t k;
+    pin_self(w->cpu);
     for (k = w->lo; k < w->hi; ++k) {
         const int8_t *rd = w->reads + w->read_off[k];
         int32_t rl = (int32_t)(w->read_off[k + 1] - w->read_off[k]);
@@ -64,11 +78,11 @@ static void *worker(void *arg)
 }
 
 /* returns 0 on success; seconds_out = wall time of the threaded section */
-int ipx_cpu_baseline(const char *libpath, const char *prefix, const int8_t *reads,
+int ipx_cpu_baseline_pinned(const char *libpath, const char *prefix, const int8_t *reads,
                      const int64_t *read_off, const int8_t *refs, const int64_t *ref_off,
                      const int32_t *ref_id, const uint8_t *gapO, const uint8_t *gapE,
-                     const int8_t *mat, int64_t n_jobs, int nthreads, double *seconds_out,
-                     int64_t *checksum_out, int64_t *cigar_ops_out)
+                     const int8_t *mat, int64_t n_jobs, int nthreads, const int32_t *cpus /* nthreads ids or NULL */,
+                     double *seconds_out, int64_t *checksum_out, int64_t *cigar_ops_out)
 {
     char name[128];
     void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
@@ -95,6 +109,7 @@ int ipx_cpu_baseline(const char *libpath, const char *prefix, const int8_t *read
         w->ref_id = ref_id; w->gapO = gapO; w->gapE = gapE; w->mat = mat;
         w->lo = n_jobs * t / nthreads;
         w->hi = n_jobs * (t + 1) / nthreads;
+        w->cpu = cpus ? cpus[t] : -1;
     }
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker, &ws[t]);
@@ -108,6 +123,16 @@ int ipx_cpu_baseline(const char *libpath, const char *prefix, const int8_t *read
     return 0;
 }
 
+int ipx_cpu_baseline(const char *libpath, const char *prefix, const int8_t *reads,
+                     const int64_t *read_off, const int8_t *refs, const int64_t *ref_off,
+                     const int32_t *ref_id, const uint8_t *gapO, const uint8_t *gapE,
+                     const int8_t *mat, int64_t n_jobs, int nthreads, double *seconds_out,
+                     int64_t *checksum_out, int64_t *cigar_ops_out)
+{
+    return ipx_cpu_baseline_pinned(libpath, prefix, reads, read_off, refs, ref_off, ref_id, gapO, gapE, mat, n_jobs,
+                                   nthreads, NULL, seconds_out, checksum_out, cigar_ops_out);
+}
+
 /* ---- full per-job results from the CPU checker (parity stress tests) -------------------------------
  * Same threading as above; writes one 32-byte record per job with the layout of ipx_result
  * (include/indelpost_hip.h) except that cigar_off carries an FNV-1a hash of the BAM-encoded ops. */
@@ -119,7 +144,7 @@ typedef struct {
     uint8_t flag, is_null;
 } rec_t;
 
-typedef struct { work_t w; rec_t *out; } work2_t;
+typedef struct { work_t w; rec_t *out; uint32_t *wsum; /* optional: sum_q cigar[q]*(q+1) per job */ } work2_t;
 
 static void *worker2(void *arg)
 {
@@ -146,6 +171,11 @@ static void *worker2(void *arg)
             r->cigar_len = (uint16_t)(a->cigar ? a->cigarLen : 0);
             for (q = 0; a->cigar && q < a->cigarLen; ++q) { h ^= a->cigar[q]; h *= 16777619u; }
             r->cigar_hash = h;
+            if (x->wsum) {
+                uint32_t ws = 0;
+                for (q = 0; a->cigar && q < a->cigarLen; ++q) ws += a->cigar[q] * (uint32_t)(q + 1);
+                x->wsum[k] = ws;
+            }
             w->adestroy(a);
         }
         w->idestroy(p);
@@ -153,10 +183,10 @@ static void *worker2(void *arg)
     return NULL;
 }
 
-int ipx_cpu_batch_results(const char *libpath, const char *prefix, const int8_t *reads,
+int ipx_cpu_batch_results_w(const char *libpath, const char *prefix, const int8_t *reads,
                           const int64_t *read_off, const int8_t *refs, const int64_t *ref_off,
                           const int32_t *ref_id, const uint8_t *gapO, const uint8_t *gapE,
-                          const int8_t *mat, int64_t n_jobs, int nthreads, void *out_records)
+                          const int8_t *mat, int64_t n_jobs, int nthreads, void *out_records, uint32_t *out_wsum)
 {
     char name[128];
     void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
@@ -178,10 +208,21 @@ int ipx_cpu_batch_results(const char *libpath, const char *prefix, const int8_t 
         w->ref_id = ref_id; w->gapO = gapO; w->gapE = gapE; w->mat = mat;
         w->lo = n_jobs * t / nthreads;
         w->hi = n_jobs * (t + 1) / nthreads;
+        w->cpu = -1;
         ws[t].out = (rec_t *)out_records;
+        ws[t].wsum = out_wsum;
     }
     for (t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker2, &ws[t]);
     for (t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     free(th); free(ws); dlclose(h);
     return 0;
+}
+
+int ipx_cpu_batch_results(const char *libpath, const char *prefix, const int8_t *reads,
+                          const int64_t *read_off, const int8_t *refs, const int64_t *ref_off,
+                          const int32_t *ref_id, const uint8_t *gapO, const uint8_t *gapE,
+                          const int8_t *mat, int64_t n_jobs, int nthreads, void *out_records)
+{
+    return ipx_cpu_batch_results_w(libpath, prefix, reads, read_off, refs, ref_off, ref_id, gapO, gapE, mat, n_jobs,
+                                   nthreads, out_records, NULL);
 }

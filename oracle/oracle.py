@@ -93,16 +93,20 @@ class Backend:
         self._idestroy(prof)
         return out
 
-    def cpu_baseline(self, reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mat, nthreads):
-        """Time the reference per-read loop on `nthreads` threads (cpu_baseline.c).
-        Returns (seconds, sum(score1), sum(cigarLen))."""
+    def cpu_baseline(self, reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mat, nthreads, cpus=None):
+        """Time the reference per-read loop on `nthreads` threads (cpu_baseline.c); `cpus`: one logical CPU id
+        per thread to pin it to, or None.  Returns (seconds, sum(score1), sum(cigarLen))."""
         h = C.CDLL(PORT_LIB)
-        f = h.ipx_cpu_baseline
+        f = h.ipx_cpu_baseline_pinned
         f.restype = C.c_int
-        f.argtypes = [C.c_char_p, C.c_char_p] + [C.c_void_p] * 8 + [C.c_int64, C.c_int,
+        f.argtypes = [C.c_char_p, C.c_char_p] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_void_p,
                                                                      C.POINTER(C.c_double),
                                                                      C.POINTER(C.c_int64),
                                                                      C.POINTER(C.c_int64)]
+        pin = None
+        if cpus is not None:
+            pin = np.ascontiguousarray(list(cpus)[:nthreads], np.int32)
+            assert len(pin) == nthreads
         reads = np.ascontiguousarray(reads, np.int8)
         read_off = np.ascontiguousarray(read_off, np.int64)
         refs = np.ascontiguousarray(refs, np.int8)
@@ -115,10 +119,58 @@ class Backend:
         sec, chk, ops = C.c_double(), C.c_int64(), C.c_int64()
         rc = f(self.path.encode(), self.prefix.encode(), reads.ctypes.data, read_off.ctypes.data,
                refs.ctypes.data, ref_off.ctypes.data, ref_id.ctypes.data, go.ctypes.data,
-               ge.ctypes.data, mat.ctypes.data, n, nthreads, C.byref(sec), C.byref(chk), C.byref(ops))
+               ge.ctypes.data, mat.ctypes.data, n, nthreads, None if pin is None else pin.ctypes.data,
+               C.byref(sec), C.byref(chk), C.byref(ops))
         if rc != 0:
             raise RuntimeError("ipx_cpu_baseline failed: %d" % rc)
         return sec.value, chk.value, ops.value
+
+
+def host_topology():
+    """What the CPU baseline runs on: model name, sockets, and ONE logical CPU per physical core of the socket
+    that holds the first CPU this process may use (/sys/devices/system/cpu/*/topology, lscpu's source), plus the
+    cgroup CPU quota when there is one (a container may see every CPU and still be throttled to a few)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    pkg, core = {}, {}
+    for c in allowed:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            pkg[c] = int(open(base + "physical_package_id").read())
+            core[c] = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg[c], core[c] = 0, c
+    sockets = sorted(set(pkg.values()))
+    s0 = pkg[allowed[0]] if allowed else 0
+    seen, phys = set(), []
+    for c in allowed:
+        if pkg[c] == s0 and core[c] not in seen:
+            seen.add(core[c])
+            phys.append(c)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    quota = q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {"model": model, "sockets": len(sockets), "logical_cpus_allowed": len(allowed),
+            "physical_cores_socket0": len(phys), "socket0_core_cpus": phys, "cgroup_cpu_quota": quota}
 
 
 CPU_REC = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"), ("ref_end1", "<i4"),
@@ -126,23 +178,26 @@ CPU_REC = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"),
                     ("cigar_len", "<u2"), ("flag", "u1"), ("is_null", "u1")])
 
 
-def cpu_batch_results(backend, jobs, mat, nthreads):
+def cpu_batch_results(backend, jobs, mat, nthreads, with_wsum=False):
     """Per-job results of a whole job table from the CPU checker (cpu_baseline.c), threaded.
-    `jobs` is an indelpost_amd.batch.JobTable; returns a CPU_REC array (cigar as FNV-1a hash)."""
+    `jobs` is an indelpost_amd.batch.JobTable; returns a CPU_REC array (cigar as FNV-1a hash); with_wsum: also
+    the per-job weighted op sum  sum_q cigar[q]*(q+1)  (uint32) that record_digest() uses."""
     h = C.CDLL(PORT_LIB)
-    f = h.ipx_cpu_batch_results
+    f = h.ipx_cpu_batch_results_w
     f.restype = C.c_int
-    f.argtypes = [C.c_char_p, C.c_char_p] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_void_p]
+    f.argtypes = [C.c_char_p, C.c_char_p] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
     out = np.zeros(jobs.n_jobs, CPU_REC)
+    wsum = np.zeros(jobs.n_jobs, np.uint32) if with_wsum else None
     mat = np.ascontiguousarray(mat, np.int8)
     reads = np.concatenate([jobs.reads, np.zeros(8, np.int8)])
     refs = np.concatenate([np.zeros(8, np.int8), jobs.refs, np.zeros(8, np.int8)])
     rc = f(backend.path.encode(), backend.prefix.encode(), reads.ctypes.data, jobs.read_off.ctypes.data,
            refs.ctypes.data + 8, jobs.ref_off.ctypes.data, jobs.ref_id.ctypes.data, jobs.gap_open.ctypes.data,
-           jobs.gap_ext.ctypes.data, mat.ctypes.data, jobs.n_jobs, nthreads, out.ctypes.data)
+           jobs.gap_ext.ctypes.data, mat.ctypes.data, jobs.n_jobs, nthreads, out.ctypes.data,
+           None if wsum is None else wsum.ctypes.data)
     if rc != 0:
         raise RuntimeError("ipx_cpu_batch_results failed: %d" % rc)
-    return out
+    return (out, wsum) if with_wsum else out
 
 
 def fnv1a_ops(ops):

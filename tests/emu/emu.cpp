@@ -168,6 +168,7 @@ struct EmuBackend {
     int sweep_grid(int, uint64_t, int) const { return 2; }
     int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
+    void note_dp(int, int, int, int) {}
     template <class K, class... A>
     void launch(int kclass, K kern, int grid, int block, int lds, A... args)
     {

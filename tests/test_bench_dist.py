@@ -1,7 +1,10 @@
-"""The N>1 path on CPU: two ranks over gloo (torch.distributed.run, 127.0.0.1), each aligning its
-shard of the job table with the emulated kernels; rank 0 gathers and compares with the unsharded run.
-No data-path collective exists in the product (jobs are independent) -- this covers the sharding,
-the rank/launch plumbing bench.py relies on, and the host-side gather."""
+"""The N>1 path on CPU: two ranks over gloo (torch.distributed.run, 127.0.0.1).
+
+1. bench.py --sharded --backend emu: the real bench driver -- ONE job table cut with JobTable.shard, every rank aligning
+   its shard (emulated kernels in place of the GPU), rank 0 gathering inside the timed loop -- must print one JSON line.
+2. a bespoke worker that compares the gathered records with the unsharded run, job for job.
+No data-path collective exists in the product (jobs are independent)."""
+import json
 import os
 import subprocess
 import sys
@@ -9,11 +12,25 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_gloo_shard_and_gather(emu, tmp_path):
-    out = tmp_path / "result.txt"
+def _torchrun(args, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "dist_worker.py"), str(out)]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_two_rank_gloo_bench_sharded(emu, hip_lib):
+    p = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--sharded", "--backend", "emu"], 29519)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    rec = json.loads(line[0])
+    assert rec["mode"] == "sharded" and rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["jobs_total"] == 48 and rec["sum_score1"] > 0
+
+
+def test_two_rank_gloo_shard_and_gather(emu, tmp_path):
+    out = tmp_path / "result.txt"
+    p = _torchrun([os.path.join(ROOT, "tests", "dist_worker.py"), str(out)], 29517)
     assert p.returncode == 0, p.stderr[-2000:]
     assert out.read_text().startswith("OK 14")

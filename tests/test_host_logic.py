@@ -127,3 +127,77 @@ def test_out_of_scope_shells_say_so():
     for name in ("Variant", "VariantAlignment", "Contig"):
         with pytest.raises(NotImplementedError):
             getattr(ip, name)()
+
+
+def test_shard_paths_keep_every_job_intact():
+    """JobTable.shard: the three window-shipping paths (all windows, dense id range, gathered) give tables whose
+    jobs see the same read, window and penalties as in the parent table."""
+    rng = np.random.default_rng(6)
+    n_refs, n_jobs = 600, 900
+    refs = [rng.integers(0, 4, int(rng.integers(1500, 2600))).astype(np.int8) for _ in range(n_refs)]   # > 1 MiB of windows
+    reads = [rng.integers(0, 4, int(rng.integers(5, 40))).astype(np.int8) for _ in range(n_jobs)]
+
+    def check(jobs, lo, hi):
+        sh = jobs.shard(lo, hi)
+        assert sh.n_jobs == hi - lo
+        for k in range(0, hi - lo, 7):
+            j = lo + k
+            assert np.array_equal(sh.reads[sh.read_off[k]:sh.read_off[k + 1]], jobs.reads[jobs.read_off[j]:jobs.read_off[j + 1]])
+            a, b = sh.ref_id[k], jobs.ref_id[j]
+            assert np.array_equal(sh.refs[sh.ref_off[a]:sh.ref_off[a + 1]], jobs.refs[jobs.ref_off[b]:jobs.ref_off[b + 1]])
+            assert sh.gap_open[k] == jobs.gap_open[j] and sh.gap_ext[k] == jobs.gap_ext[j]
+        return sh
+
+    go = rng.integers(0, 9, n_jobs)
+    sorted_ids = np.sort(rng.integers(0, n_refs, n_jobs))                     # a table sorted by locus: dense id ranges
+    jobs = JobTable.from_sequences(reads, refs, sorted_ids, go, 1, encoded=True)
+    sh = check(jobs, 100, 400)
+    assert sh.n_refs < n_refs and len(sh.refs) < len(jobs.refs)                # only the range travelled
+    scattered = rng.integers(0, n_refs, n_jobs)
+    scattered[::2] = np.where(scattered[::2] % 2 == 0, 0, n_refs - 1)          # ids span everything, most windows unused
+    jobs2 = JobTable.from_sequences(reads, refs, scattered, go, 1, encoded=True)
+    sh2 = check(jobs2, 0, 60)
+    assert sh2.n_refs <= 60 and len(sh2.refs) < len(jobs2.refs) // 4           # gathered
+    assert check(jobs2, 10, 10).n_jobs == 0
+    small = JobTable.from_sequences(reads[:20], refs[:3], [i % 3 for i in range(20)], 3, 1, encoded=True)
+    assert check(small, 5, 15).n_refs == 3                                     # small window set: shipped whole
+
+
+def test_result_digest_agrees_with_the_cpu_checker(emu, oracle_mod):
+    """BatchResult.digest() (what bench.py compares with tests/golden/bench_digests.json) equals the digest computed
+    from the CPU checker's records on the same table, and notices a single changed CIGAR op."""
+    from indelpost_amd.batch import record_digest
+    rng = np.random.default_rng(9)
+    w = rng.integers(0, 4, 220).astype(np.int8)
+    reads = []
+    for i in range(40):
+        r = w[i * 3:i * 3 + 70].copy()
+        r[rng.integers(0, 70)] ^= 1
+        if i % 4 == 0:
+            r = np.concatenate([r[:30], r[34:]])
+        reads.append(r)
+    jobs = JobTable.from_sequences(reads, [w], [0] * 40, 3, 1, encoded=True)
+    res = emu(0, 3, 2).align(jobs)
+    rec, wsum = oracle_mod.cpu_batch_results(oracle_mod.Backend("port"), jobs, oracle_mod.dna_matrix(3, 2), 2, with_wsum=True)
+    assert res.digest() == record_digest(rec, wsum)
+    i = int(np.flatnonzero(res.records["cigar_len"] > 1)[0])
+    res.cigar_pool[int(res.records["cigar_off"][i]) + 1] += 16
+    assert res.digest() != record_digest(rec, wsum)
+
+
+def test_synthetic_config_tables(hip_lib):
+    """the multi-window generator behind bench.py's config-4 / config-5 shapes: deterministic, shapes as SURVEY 8d says"""
+    from indelpost_amd import synth
+    a, b = synth.config4_jobs(n_windows=5, reads_per_window=60), synth.config4_jobs(n_windows=5, reads_per_window=60)
+    assert a.n_jobs == 300 and a.n_refs == 5 and np.array_equal(a.reads, b.reads) and np.array_equal(a.refs, b.refs)
+    wl = np.diff(a.ref_off)
+    assert wl.min() >= 200 and wl.max() <= 600
+    lens = np.diff(a.read_off).reshape(5, 6, 10)
+    for k, rl in enumerate((75, 100, 125, 150, 200, 250)):
+        assert (lens[:, k, :] == np.minimum(rl, wl)[:, None]).all()
+    assert (a.ref_id == np.repeat(np.arange(5), 60)).all() and a.reads.min() >= 0 and a.reads.max() <= 3
+    c = synth.config5_jobs(n_loci=3, reads_per_locus=4)
+    assert c.n_jobs == 72 and c.n_refs == 12 and (np.diff(c.ref_off) == 300).all() and (np.diff(c.read_off) == 150).all()
+    assert [tuple(x) for x in np.stack([c.gap_open[:6], c.gap_ext[:6]], 1).tolist()] == synth.PENALTY_GRID
+    assert (c.ref_id == np.repeat(np.arange(12), 6)).all()
+    assert np.array_equal(c.reads[:150], c.reads[150 * 5:150 * 6]) and not np.array_equal(c.reads[:150], c.reads[900:1050])
