@@ -110,6 +110,13 @@ const char *ipx_last_error(void);
  * flag/filters/filterd: as ssw_align (ssw.c:821-823); score_size: as ssw_init (ssw.c:793-802). */
 int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int filterd, int score_size);
 
+/* Speed-only routing switches (bit mask; 0 = everything on).  Results never depend on them -- each proof or kernel
+ * variant they disable has an exact fallback -- which is what the test suite uses them for:
+ *   1 no 16-bit pass before the 8-bit one    2 LDS-staged profile instead of register selectors
+ *   4 no upper-bound (bracket) stage         8 one traceback launch per band width
+ *  16 column maxima in global scratch instead of LDS */
+int ipx_set_routing(ipx_ctx *c, int flags);
+
 /* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,
  * ref_off: n_refs+1 offsets; ref_id[j]: window of job j; gap_open/gap_ext: already narrowed to
  * uint8 (ssw.h:129-130); mask_len: per job, or NULL for max(15, readLen/2) (sswpy.pyx:209-211). */

@@ -13,10 +13,14 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libindelpost_hip.so")
-SRC = os.path.join(PKG_DIR, "csrc", "ipx_runtime.hip")
-HEADERS = [os.path.join(PKG_DIR, "csrc", h) for h in
-           ("ipx_simt.h", "ipx_types.h", "ipx_kernels.h", "ipx_pipeline.h")] + [
+CSRC = os.path.join(PKG_DIR, "csrc")
+SRC = os.path.join(CSRC, "ipx_runtime.hip")
+# the library is several translation units (compiled in parallel): the runtime + every other kernel, and eight
+# units holding the explicit instantiations of the striped-DP kernel families (csrc/ipx_kernels.h, end of file)
+UNITS = [SRC] + [os.path.join(CSRC, "ipx_dp_%s.hip" % u) for u in "abcdefgh"]
+HEADERS = [os.path.join(CSRC, h) for h in ("ipx_simt.h", "ipx_types.h", "ipx_kernels.h", "ipx_pipeline.h")] + [
     os.path.join(os.path.dirname(PKG_DIR), "include", "indelpost_hip.h")]
+BUILD_DIR = os.path.join(CSRC, "build")
 
 # numpy view of ipx_result (32 bytes)
 RESULT_DTYPE = np.dtype([
@@ -29,7 +33,7 @@ EXPORTS = [
     # reference-compatible four-call interface (ssw.h:86,91,126-134,139)
     "ssw_init", "init_destroy", "ssw_align", "align_destroy",
     # batched interface
-    "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_upload",
+    "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_set_routing", "ipx_upload",
     "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch", "ipx_set_profiling",
     "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts",
     "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars",
@@ -40,15 +44,20 @@ class IpxError(RuntimeError):
     pass
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def _stale(target, sources):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in [SRC] + HEADERS)
+    t = os.path.getmtime(target)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in sources)
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+def needs_build():
+    return _stale(LIB_PATH, UNITS + HEADERS)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU): one object per translation unit,
+    in parallel, then one link."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -56,11 +65,33 @@ def build(force=False, verbose=False):
         if os.path.exists(LIB_PATH):
             return LIB_PATH          # prebuilt library travelled with the tree
         raise IpxError("hipcc not found and %s is not built" % LIB_PATH)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB_PATH, SRC]
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    objs, todo = [], []
+    for src in UNITS:
+        obj = os.path.join(BUILD_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            todo.append([hipcc] + flags + ["-c", src, "-o", obj])
+    jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 2)))
+    running = []
+    for cmd in todo:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        running.append((cmd, subprocess.Popen(cmd)))
+        while len([p for _, p in running if p.poll() is None]) >= jobs:
+            running[0][1].wait() if running[0][1].poll() is None else None
+            for _, p in running:
+                if p.poll() is None:
+                    p.wait()
+                    break
+    for cmd, p in running:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB_PATH
 
 
@@ -84,6 +115,8 @@ def lib():
     L.ipx_destroy.restype = None
     L.ipx_last_error.restype = C.c_char_p
     L.ipx_set_params.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ipx_set_routing.argtypes = [vp, C.c_int]
+    L.ipx_set_routing.restype = C.c_int
     L.ipx_upload.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32]
     L.ipx_run.argtypes = [vp]
     L.ipx_sync.argtypes = [vp]
@@ -108,7 +141,7 @@ def lib():
     L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
     L.ipx_synth_mixed.restype = i64
     L.ipx_synth_mixed.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
-    for f in ("ipx_set_params", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch",
+    for f in ("ipx_set_params", "ipx_set_routing", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch",
               "ipx_set_profiling", "ipx_kernel_times"):
         getattr(L, f).restype = C.c_int
     _lib = L

@@ -15,6 +15,10 @@ from ._lib import RESULT_DTYPE, IpxError
 
 _OPS = "MIDNSHP=X"
 
+# speed-only routing switches of the library (ipx_set_routing; csrc/ipx_types.h IPX_ROUTE_*): every combination gives
+# identical results -- the tests run them all
+ROUTE_NO_WORD_FIRST, ROUTE_NO_PERM_PROFILE, ROUTE_NO_BRACKET, ROUTE_TB_NO_FUSE, ROUTE_NO_MC_LDS = 1, 2, 4, 8, 16
+
 # DNA_BASE_LUT of the reference (sswpy.pyx:16-25): A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, else 4.
 # Bytes >= 128 index the reference's table out of bounds (undefined); they map to N here.
 DNA_LUT = np.full(256, 4, np.int8)
@@ -243,6 +247,10 @@ class GpuAligner:
         self.matrix = m
         self._check(self._L.ipx_set_params(self._ctx, _p(m), flag, filters, filterd, score_size), "ipx_set_params")
 
+    def set_routing(self, flags):
+        """speed-only routing switches (ROUTE_*): which proofs / kernel variants are tried; never changes a result"""
+        self._check(self._L.ipx_set_routing(self._ctx, int(flags)), "ipx_set_routing")
+
     # -- staged interface (bench.py: inputs resident in HBM before the timed region) --
     def upload(self, jobs):
         self._jobs = jobs   # keep host arrays alive
@@ -369,6 +377,10 @@ class MultiStreamAligner:
         for p in self.parts:
             p.set_scoring(*a, **k)
         self.matrix = self.parts[0].matrix
+
+    def set_routing(self, flags):
+        for p in self.parts:
+            p.set_routing(flags)
 
     def upload(self, jobs):
         k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream

@@ -38,6 +38,16 @@
 #include "ipx_simt.h"
 #include "ipx_types.h"
 
+// The library is built from several translation units (the ~400 instantiations of k_dp_pass take minutes to compile
+// in one): csrc/ipx_dp_*.hip define IPX_DP_TEMPLATES_ONLY and instantiate families of k_dp_pass explicitly
+// (IPX_DP_FAMILY at the end of this file); ipx_runtime.hip defines IPX_EXTERN_KERNELS, declares them extern and
+// owns every other kernel.  The emulator build (tests/emu) is one translation unit with implicit instantiation.
+#if defined(IPX_DP_TEMPLATES_ONLY)
+#define IPX_AUX_KERNELS 0
+#else
+#define IPX_AUX_KERNELS 1
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
@@ -91,6 +101,7 @@ IPX_DEV bool rev_needed(const IpxBatch &b, unsigned score1)   // ssw.c:872
     return !(b.flag == 0 || (b.flag == 2 && score1 < b.filters));
 }
 
+#if IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
 // k_pack_refs: copy every window to a 4-byte aligned, padded slot; codes outside 0..4 become 4 (N)
 // ------------------------------------------------------------------------------------------------
@@ -126,55 +137,65 @@ IPX_KERNEL void k_init(IpxBatch b)
     }
 }
 
+#endif // IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
-// planner: which jobs take part in a pass, and in which segLen class
+// planner: which jobs take part in a pass, and in which class
 // ------------------------------------------------------------------------------------------------
-// returns the class (segLen) of job i for `pass`, or -1 when the job does not take part
-IPX_DEV int plan_class(const IpxBatch &b, int pass, int64_t i)
+// The pass a job's record says it takes next, as pass * 256 + class, or -1 when there is none.  class = number of
+// striped segments of that pass (+ IPX_SLOW_BASE for a job with gap_open <= gap_ext, which needs a kernel with the
+// reference's stepped lazy-F loop).  This ONE function is the authority: the kernels that write a record count it into
+// the pass it names (plan_note), and the scatter kernel of a pass collects exactly the jobs whose record names it.
+IPX_DEV int next_pass_key(const IpxBatch &b, const IpxResult &r, int readLen, bool slow)
 {
-    const int readLen = (int)(b.read_off[i + 1] - b.read_off[i]);
-    const int refLen = b.ref_len[b.ref_id[i]];
-    const IpxResult r = b.res[i];
-    int L, lanes, ncol;
-    switch (pass) {
-    case IPX_PASS_WORD_FIRST:
-        if (b.score_size != 2 || r.mode != IPX_MODE_PENDING || b.word_first_len <= 0 || readLen < b.word_first_len) return -1;
-        L = readLen; lanes = 8; ncol = refLen;
+    int pass, L = readLen, lanes = 16;
+    switch (r.mode) {
+    case IPX_MODE_PENDING:
+        if (b.score_size == 1) { pass = IPX_PASS_WORD_FWD; lanes = 8; }                      // 16-bit profile only (ssw.c:853-855)
+        else if (b.score_size == 2 && b.word_first_len > 0 && readLen >= b.word_first_len) { pass = IPX_PASS_WORD_FIRST; lanes = 8; }
+        else pass = IPX_PASS_BYTE_LOW;                                                       // ssw.c:842-843
         break;
-    case IPX_PASS_BYTE_FWD:
-        if (b.score_size == 1 || (r.mode != IPX_MODE_PENDING && r.mode != IPX_MODE_NEED_BYTE_CHECK)) return -1;
-        if (r.mode == IPX_MODE_PENDING && readLen < b.byte_safe_len) return -1;      // cannot overflow: exact stage directly
-        L = readLen; lanes = 16; ncol = refLen;
+    case IPX_MODE_NEED_BYTE_CHECK: pass = IPX_PASS_BYTE_CHECK; break;
+    case IPX_MODE_NEED_BYTE_HIGH: pass = IPX_PASS_BYTE_HIGH; break;
+    case IPX_MODE_NEED_BYTE_EXACT:
+    case IPX_MODE_NEED_BYTE_EXACT_W: pass = IPX_PASS_BYTE_EXACT; break;
+    case IPX_MODE_NEED_WORD: pass = IPX_PASS_WORD_FWD; lanes = 8; break;                     // ssw.c:844-847
+    case IPX_MODE_BYTE:
+        if (!rev_needed(b, r.score1)) return -1;
+        pass = IPX_PASS_BYTE_REV; L = r.read_end1 + 1;                                       // ssw.c:875-886
         break;
-    case IPX_PASS_BYTE_FWD_EXACT:
-        if (r.mode != IPX_MODE_NEED_BYTE_EXACT && r.mode != IPX_MODE_NEED_BYTE_EXACT_W &&
-            !(r.mode == IPX_MODE_PENDING && b.score_size != 1 && readLen < b.byte_safe_len)) return -1;
-        L = readLen; lanes = 16; ncol = refLen;
+    case IPX_MODE_WORD:
+        if (!rev_needed(b, r.score1)) return -1;
+        pass = IPX_PASS_WORD_REV; L = r.read_end1 + 1; lanes = 8;
         break;
-    case IPX_PASS_WORD_FWD:
-        if (!((b.score_size == 1 && r.mode == IPX_MODE_PENDING) || r.mode == IPX_MODE_NEED_WORD)) return -1;
-        L = readLen; lanes = 8; ncol = refLen;
-        break;
-    case IPX_PASS_BYTE_REV:
-        if (r.mode != IPX_MODE_BYTE || !rev_needed(b, r.score1)) return -1;
-        L = r.read_end1 + 1; lanes = 16; ncol = r.ref_end1 + 1;
-        break;
-    default: // IPX_PASS_WORD_REV
-        if (r.mode != IPX_MODE_WORD || !rev_needed(b, r.score1)) return -1;
-        L = r.read_end1 + 1; lanes = 8; ncol = r.ref_end1 + 1;
-        break;
+    default: return -1;                                       // FAIL, WORD_UNPROVEN (k_prove_overflow moves those on)
     }
     if (L < 0) L = 0;
     const int cls = (L + lanes - 1) / lanes;
     if (cls > IPX_MAX_SEG) { atomic_or_u32(b.status, IPX_STATUS_READ_TOO_LONG); return -1; }
-    if (ncol > IPX_MAX_REFLEN) { atomic_or_u32(b.status, IPX_STATUS_REF_TOO_LONG); return -1; }
-    return cls;
+    return pass * 256 + cls + (slow ? IPX_SLOW_BASE : 0);
 }
 
-IPX_KERNEL void k_plan_zero(IpxPlan p)
+// class of job i in `pass`, or -1 when the job does not take part
+IPX_DEV int plan_class(const IpxBatch &b, int pass, int64_t i)
 {
-    const int t = IPX_TID;
-    if (t < IPX_NUM_CLASSES) { p.count[t] = 0; p.cursor[t] = 0; }
+    const int readLen = (int)(b.read_off[i + 1] - b.read_off[i]);
+    const int key = next_pass_key(b, b.res[i], readLen, b.gap_open[i] <= b.gap_ext[i]);
+    return (key >= 0 && (key >> 8) == pass) ? (key & 255) : -1;
+}
+
+// Count a job into the pass its record names.  EVERY lane of the wave calls it (key -1: nothing to count); jobs of
+// the wave with the same key share one atomic.
+IPX_DEV void plan_note(const IpxBatch &b, int key)
+{
+    const int lane = lane_id();
+    uint64_t todo = xl_ballot(key >= 0);
+    while (todo) {                                         // one round per distinct key in the wave
+        const int leader = __builtin_ffsll((long long)todo) - 1;
+        const int k = (int)xl_shfl((uint32_t)key, leader);
+        const uint64_t m = xl_ballot(key == k);
+        if (lane == leader) (void)atomic_add_u32(&b.plan_counts[(k >> 8) * (2 * IPX_NUM_CLASSES) + (k & 255)], (uint32_t)__builtin_popcountll(m));
+        todo &= ~m;
+    }
 }
 
 // Jobs of a wave that fall into the same class share ONE atomic: the wave's first lane of the class
@@ -197,74 +218,79 @@ IPX_DEV uint32_t wave_class_slot(uint32_t *counter, int cls)
     return slot;
 }
 
-// Block-level version: the waves of a block first add up in LDS (one LDS atomic per class per wave), then ONE thread
-// per class adds the block's total to the global counter and publishes the base -- 8x fewer same-address global
-// atomics with 512-thread blocks.  All threads of the block must call it (barriers).  lds: 160 uint32.
-IPX_DEV uint32_t block_class_slot(uint32_t *counter, int cls, uint32_t *lds)
-{
-    uint32_t *cnt = lds, *base = lds + 80;
-    const int tid = IPX_TID;
-    if (tid < 80) cnt[tid] = 0;
-    IPX_SYNC();
-    const uint32_t local = wave_class_slot(cnt, cls);
-    IPX_SYNC();
-    if (tid < 80 && cnt[tid] != 0) base[tid] = atomic_add_u32(&counter[tid], cnt[tid]);
-    IPX_SYNC();
-    return cls >= 0 ? base[cls] + local : 0u;
-}
-#if defined(IPX_CPU_EMU)
-#define IPX_PLAN_BLOCK 128          // (two waves: enough to exercise the block-level path, cheaper to emulate)
-#else
-#define IPX_PLAN_BLOCK 512
-#endif
-#define IPX_PLAN_LDS 640
+// Planner kernels are ONE wave per block and a handful of registers: on a GPU busy with other streams' DP blocks (which
+// fill the register files) a one-wave block is resident as soon as any single DP wave retires, where a 512-thread block
+// had to wait for room on all four SIMDs of one CU at once (r01: k_plan_count was the top row of the 4-stream profile).
+#define IPX_PLAN_BLOCK 64
+#define IPX_PLAN_LDS (8 * (IPX_NUM_CLASSES + 2))
 
-IPX_KERNEL void k_plan_count(IpxBatch b, IpxPlan p, int pass)
+#if IPX_AUX_KERNELS
+// count the jobs of `pass` from their records: used for the static passes (once per resident batch) and for a
+// pass whose jobs come straight from k_init (16-bit only profiles)
+IPX_KERNEL void k_plan_count(IpxBatch b, int pass)
 {
     const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
     const int64_t rounds = (b.n_jobs + stride - 1) / stride;
     for (int64_t q = 0; q < rounds; ++q) {                 // every lane runs every round (wave-wide ballots)
         const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
         const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
-        (void)block_class_slot(p.count, cls, (uint32_t *)IPX_LDS_BASE);
+        plan_note(b, cls >= 0 ? pass * 256 + cls : -1);
     }
 }
 
-// one wave: exclusive scans over the 65 classes -> slot and tile offsets (NA = alignments per tile)
-IPX_KERNEL void k_plan_scan(IpxPlan p, int na, int pass)
+// Scatter the jobs of `pass` into perm, grouped by class.  Every block first turns the class counts into slot and tile
+// offsets for itself (exclusive scans over the IPX_NUM_CLASSES classes by one wave; NA = alignments per tile); block 0
+// also publishes them for the DP kernels of the pass.
+IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass, int na)
 {
-    if (IPX_TID == 0) {
-        uint32_t so = 0, to = 0;
-        uint32_t *st = p.stats ? p.stats + pass * (IPX_NUM_CLASSES + 1) : nullptr;
-        for (int c = 0; c < IPX_NUM_CLASSES; ++c) {
-            p.cls_off[c] = so;
-            p.tile_off[c] = to;
-            so += p.count[c];
-            const uint32_t t = (p.count[c] + (uint32_t)na - 1u) / (uint32_t)na;
-            to += t;
-            if (st) st[c] = t;
+    uint32_t *cls_off = (uint32_t *)IPX_LDS_BASE, *tile_off = cls_off + IPX_NUM_CLASSES + 1;
+    const int lane = lane_id();
+    {
+        uint32_t c[3], s = 0, t = 0;
+        IPX_UNROLL
+        for (int k = 0; k < 3; ++k) {
+            const int cl = 3 * lane + k;
+            c[k] = cl < IPX_NUM_CLASSES ? p.count[cl] : 0u;
+            s += c[k];
+            t += (c[k] + (uint32_t)na - 1u) / (uint32_t)na;
         }
-        p.cls_off[IPX_NUM_CLASSES] = so;
-        p.tile_off[IPX_NUM_CLASSES] = to;
-        if (st) st[IPX_NUM_CLASSES] = to;
+        uint32_t si = s, ti = t;                           // inclusive scans over the lanes
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ys = xl_shfl(si, lane >= d ? lane - d : lane), yt = xl_shfl(ti, lane >= d ? lane - d : lane);
+            if (lane >= d) { si += ys; ti += yt; }
+        }
+        uint32_t so = si - s, to = ti - t;
+        IPX_UNROLL
+        for (int k = 0; k < 3; ++k) {
+            const int cl = 3 * lane + k;
+            if (cl < IPX_NUM_CLASSES) {
+                cls_off[cl] = so; tile_off[cl] = to;
+                if (IPX_BID == 0) { p.cls_off[cl] = so; p.tile_off[cl] = to; if (p.stats) p.stats[cl] = (c[k] + (uint32_t)na - 1u) / (uint32_t)na; }
+            }
+            so += c[k];
+            to += (c[k] + (uint32_t)na - 1u) / (uint32_t)na;
+        }
+        if (lane == 63) {
+            cls_off[IPX_NUM_CLASSES] = si; tile_off[IPX_NUM_CLASSES] = ti;
+            if (IPX_BID == 0) { p.cls_off[IPX_NUM_CLASSES] = si; p.tile_off[IPX_NUM_CLASSES] = ti; if (p.stats) p.stats[IPX_NUM_CLASSES] = ti; }
+        }
     }
-}
-
-IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
-{
+    IPX_SYNC();
     const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
     const int64_t rounds = (b.n_jobs + stride - 1) / stride;
     for (int64_t q = 0; q < rounds; ++q) {
         const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
         const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
-        const uint32_t pos = block_class_slot(p.cursor, cls, (uint32_t *)IPX_LDS_BASE);
-#if defined(IPX_CPU_EMU)
-        if (cls >= 0 && (int64_t)(p.cls_off[cls] + pos) >= b.n_jobs) { fprintf(stderr, "emu: scatter out of range: pass %d job %lld cls %d off %u pos %u count %u\n", pass, (long long)i, cls, p.cls_off[cls], pos, p.count[cls]); abort(); }
-#endif
-        if (cls >= 0) p.perm[p.cls_off[cls] + pos] = (uint32_t)i;
+        const uint32_t pos = wave_class_slot(p.cursor, cls);
+        if (cls >= 0) {
+            // (a job the counting side missed would run past its class: refuse it instead)
+            if (pos >= cls_off[cls + 1] - cls_off[cls]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
+            else p.perm[cls_off[cls] + pos] = (uint32_t)i;
+        }
     }
 }
 
+#endif // IPX_AUX_KERNELS
 #if !defined(IPX_CPU_EMU) && !defined(IPX_NO_STRIPE_ASM)
 #define IPX_STRIPE_ASM 1
 #else
@@ -281,12 +307,19 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass)
 // Dynamic LDS: !PERM profile 640*SMAX B | matrix 32 B;  PERM table 64 B | matrix 64 B | column maxima 4*G*maxcols B when they fit.
 // Global: column maxima, 4*G*maxcols B per block, otherwise (forward only)
 // ------------------------------------------------------------------------------------------------
-//   LOW  = first stage of the 8-bit forward pass: in a column where some lazy-F carry of a read could
-//          meet the reference's signed-byte exit test (>= 128+gapE), that read's whole lazy-F step is
-//          skipped instead of stepped.  H then is a lower bound of the exact pass (lazy-F only ever
-//          raises H, and the recurrences are monotone), so "overflow" is certain; reads that neither
-//          overflowed nor skipped a column are exact; the rest are re-run by the exact instantiation
-//          (IPX_MODE_NEED_BYTE_EXACT).
+//   STAGE (8-bit forward pass only; IPX_STAGE_EXACT everywhere else).  The reference's lazy-F loop leaves on a SIGNED
+//          byte compare (ssw.c:311), so in a column where some carry of a read is >= 128+gapE it may stop before
+//          every carry has been passed on; what it computes there lies between "no lazy-F at all" and "every carry
+//          passed on to the end", both of which are closed forms:
+//          LOW   in such a column that read's whole lazy-F step is skipped.  H then is a lower bound of the exact pass
+//                (lazy-F only ever raises H, and the recurrences are monotone), so an overflow seen here is certain;
+//                a read that skipped no column is exact.
+//          HIGH  every carry is passed on (the closed form, whatever its size): an upper bound, cell by cell.
+//          Every output of the pass -- best score, its first column, the smallest row holding it there, the best
+//          column maximum outside the mask and its first column -- is monotone in the matrix in the sense that if
+//          LOW and HIGH agree on it the exact pass, squeezed between them, agrees too.  So a read whose LOW and HIGH
+//          outputs are all equal is CERTIFIED without stepping; the others go to the EXACT stage
+//          (IPX_MODE_NEED_BYTE_EXACT), which steps through the reference's loop.
 //   PERM = the query profile is not staged in LDS: every striped row keeps a v_perm_b32 selector of its
 //          two read letters in a register, and a column's scores come from an 8-byte table
 //          {mat[c0][A..T], mat[c1][A..T]} of the two window letters: one v_perm_b32 puts the selected
@@ -303,9 +336,11 @@ IPX_HD constexpr int ipx_dp_perm_waves(int smax)
     const int w = 512 / (4 * smax + 90);
     return w < 1 ? 1 : w;
 }
-template <int W, int SMAX, bool REV, bool EXACT, bool LOW, bool PERM = false>
-IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_classes)
+template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false>
+IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow)
 {
+    constexpr bool LOW = STAGE == IPX_STAGE_LOW, HIGH = STAGE == IPX_STAGE_HIGH;
+    static_assert(STAGE == IPX_STAGE_EXACT || (W == 16 && !REV), "the bracket stages exist for the 8-bit forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
     constexpr int NA = 2 * G;
@@ -314,7 +349,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
     // 8-bit passes, for carries in signed-compare territory.  The selector-profile kernels of the 16-bit passes
     // and of the lower-bound stage leave it out (the host launches them only when no job has gap_open <= gap_ext):
     // without that loop the H registers of a column are defined once, in place, and no copies are needed.
-    constexpr bool STEP = !(PERM && (W == 8 || LOW));
+    constexpr bool STEP = !(PERM && (W == 8 || LOW || HIGH));
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
     unsigned char *lds = IPX_LDS_BASE;
@@ -336,9 +371,10 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
         // ---- locate the tile: class (= segLen), first slot in perm, number of reads -------------
         int cls = cls_lo;
         while (tile >= p.tile_off[cls + 1]) ++cls;
-        if (!EXACT && cls < 64 && ((skip_classes >> cls) & 1ull)) continue;   // class owned by an exact-segLen launch
-        if (!EXACT && cls > SMAX) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL); continue; }   // sweep kernel sized too small (host error)
-        const int S = EXACT ? SMAX : (int)xl_first((uint32_t)cls);
+        const int seg = cls >= IPX_SLOW_BASE ? cls - IPX_SLOW_BASE : cls;      // class = segLen (+ IPX_SLOW_BASE: gap_open <= gap_ext)
+        if (!EXACT && seg < 64 && (((cls >= IPX_SLOW_BASE ? skip_slow : skip_fast) >> seg) & 1ull)) continue;   // class owned by an exact-segLen launch
+        if (!EXACT && seg > SMAX) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL); continue; }   // sweep kernel sized too small (host error)
+        const int S = EXACT ? SMAX : (int)xl_first((uint32_t)seg);
         const uint32_t first = p.cls_off[cls] + (tile - p.tile_off[cls]) * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;
         const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
@@ -638,6 +674,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     // carry would not be a lower bound, because the reference's early exit also cuts the
                     // small carries that the big one happened to dominate
                     if (LOW) { const pk16 drop = anybig & fast_static; vF &= ~drop; dropped |= drop; }
+                    else if (HIGH) dropped |= anybig & fast_static;   // every carry is passed on; remember that the read had such a column
                     else fe &= ~anybig;
                 }
                 pk16 x = xl_row_shr1(vF & fe);
@@ -796,37 +833,52 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                 int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
                 int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
                 if (BYTE) edgeR += 1;
-                uint32_t key = 0xFFFFu;                               // (score2 = 0, ref_end2 = 0)
+                uint32_t key2 = 0xFFFFu;                              // (score2 = 0, ref_end2 = 0)
                 for (int col = l; col < refLen; col += W) {
                     if (col < edgeL || col >= edgeR) {
                         const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
                         const uint32_t kk = (v << 16) | (0xFFFFu - (uint32_t)col);
-                        if (v > (key >> 16)) key = kk;
+                        if (v > (key2 >> 16)) key2 = kk;
                     }
                 }
-                key = group_umax<W>(key);
-                const bool lost = LOW && ((group_or<W>(dropped) >> (16 * h)) & 0xFFFFu) != 0;   // (all lanes take part)
+                key2 = group_umax<W>(key2);
+                const bool lost = (LOW || HIGH) && ((group_or<W>(dropped) >> (16 * h)) & 0xFFFFu) != 0;   // (all lanes take part)
+                int key = -1;                                         // pass the job takes next (plan_note below)
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
                     // a 16-bit result may already sit in the record (IPX_PASS_WORD_FIRST): an overflowing 8-bit pass keeps it
                     const bool has_word = r.mode == IPX_MODE_NEED_BYTE_CHECK || r.mode == IPX_MODE_NEED_BYTE_EXACT_W;
-                    if (BYTE && overflow) {
+                    const int s2 = maskLen >= 15 ? (int)(key2 >> 16) : 0;                                       // ssw.c:864-870
+                    const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
+                    if (HIGH) {
+                        // the record holds the lower-bound stage's outputs: equal outputs certify them (see STAGE above);
+                        // a read the upper-bound stage saw no big carry in is exact by itself
+                        const bool same = !overflow && r.score1 == (uint16_t)bh && r.ref_end1 == eref && r.read_end1 == end_read &&
+                                          r.score2 == (uint16_t)s2 && r.ref_end2 == e2;
+                        if (same || (!overflow && !lost)) {
+                            r.mode = IPX_MODE_BYTE;
+                            r.score1 = (uint16_t)bh; r.ref_end1 = eref; r.read_end1 = end_read; r.read_begin1 = -1;
+                            r.score2 = (uint16_t)s2; r.ref_end2 = e2;
+                        } else r.mode = IPX_MODE_NEED_BYTE_EXACT;
+                    } else if (BYTE && overflow) {
                         if (has_word) r.mode = IPX_MODE_WORD;
                         else if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }            // -> 16-bit pass (ssw.c:844-847)
                         else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851
-                    } else if (lost) {
+                    } else if (lost && (has_word || !b.use_bracket || L[h] < b.bracket_min_len)) {
                         r.mode = has_word ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_EXACT;             // lower bound only: exact 8-bit pass decides
                     } else {
-                        r.mode = BYTE ? IPX_MODE_BYTE : (pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD);
+                        r.mode = lost ? IPX_MODE_NEED_BYTE_HIGH                                                // lower-bound outputs kept for the upper-bound stage
+                                      : BYTE ? IPX_MODE_BYTE : (pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD);
                         r.score1 = (uint16_t)bh;
                         r.ref_end1 = eref;
                         r.read_end1 = end_read;
                         r.read_begin1 = -1;
-                        if (maskLen >= 15) { r.score2 = (uint16_t)(key >> 16); r.ref_end2 = (int)(0xFFFFu - (key & 0xFFFFu)); }
-                        else { r.score2 = 0; r.ref_end2 = -1; }                                                // ssw.c:864-870
+                        r.score2 = (uint16_t)s2; r.ref_end2 = e2;
                     }
                     b.res[job[h]] = r;
+                    key = next_pass_key(b, r, L[h], b.gap_open[job[h]] <= b.gap_ext[job[h]]);
                 }
+                plan_note(b, key);
             } else {
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
@@ -841,6 +893,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
     }
 }
 
+#if IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
 // k_prove_overflow: the reference always runs the 8-bit pass first and only then the 16-bit pass
 // (ssw.c:842-847).  For reads that will almost surely overflow we run the 16-bit pass first
@@ -883,9 +936,11 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap)
         IPX_SYNC();
         if (staged) for (int64_t q = lo + lane; q < hi; q += 64) stage[q - lo] = load_stream_i8(b.reads + q);
         IPX_SYNC();
-        if (i >= b.n_jobs) continue;
-        IpxResult r = b.res[i];
-        if (r.mode != IPX_MODE_WORD_UNPROVEN) continue;
+        int key = -1;                                              // pass the job takes next (plan_note at the end: all lanes)
+        IpxResult r;
+        r.mode = IPX_MODE_PENDING;
+        if (i < b.n_jobs) r = b.res[i];
+        if (i < b.n_jobs && r.mode == IPX_MODE_WORD_UNPROVEN) {
         const int8_t *rd = staged ? stage + (b.read_off[i] - lo) : b.reads + b.read_off[i];
         const int rid = b.ref_id[i];
         const int8_t *rf = b.refs_packed + b.refp_off[rid];
@@ -953,6 +1008,9 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap)
         }
         r.mode = proven ? IPX_MODE_WORD : IPX_MODE_NEED_BYTE_CHECK;
         b.res[i] = r;
+        key = next_pass_key(b, r, (int)(b.read_off[i + 1] - b.read_off[i]), b.gap_open[i] <= b.gap_ext[i]);
+        }
+        plan_note(b, key);
     }
 }
 
@@ -988,7 +1046,7 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                 cls = bw <= IPX_TBF_MAXBW ? bw - 1 : IPX_TBF_MAXBW;
             }
         }
-        const uint32_t slot = block_class_slot(counters, cls, (uint32_t *)IPX_LDS_BASE);
+        const uint32_t slot = wave_class_slot(counters, cls);
         if (cls >= 0) {
             if (cls < IPX_TBF_MAXBW) lists[(int64_t)cls * b.n_jobs + slot] = (uint32_t)i;
             else esc[slot] = (uint32_t)i;
@@ -1442,3 +1500,38 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
         IPX_SYNC();
     }
 }
+#endif // IPX_AUX_KERNELS
+
+// ------------------------------------------------------------------------------------------------
+// explicit instantiation of k_dp_pass, one family = segLen 0..32 of (W, REV, STAGE, PERM)
+// ------------------------------------------------------------------------------------------------
+#if !defined(IPX_CPU_EMU)
+#define IPX_DP_SIG (IpxBatch, IpxPlan, int, int, int, int, uint64_t, uint64_t)
+#define IPX_DP_FAMILY(X, W, REV, STAGE, PERM)                                                                                   \
+    X(W, 0, REV, true, STAGE, PERM) X(W, 1, REV, true, STAGE, PERM) X(W, 2, REV, true, STAGE, PERM) X(W, 3, REV, true, STAGE, PERM)       \
+    X(W, 4, REV, true, STAGE, PERM) X(W, 5, REV, true, STAGE, PERM) X(W, 6, REV, true, STAGE, PERM) X(W, 7, REV, true, STAGE, PERM)       \
+    X(W, 8, REV, true, STAGE, PERM) X(W, 9, REV, true, STAGE, PERM) X(W, 10, REV, true, STAGE, PERM) X(W, 11, REV, true, STAGE, PERM)     \
+    X(W, 12, REV, true, STAGE, PERM) X(W, 13, REV, true, STAGE, PERM) X(W, 14, REV, true, STAGE, PERM) X(W, 15, REV, true, STAGE, PERM)   \
+    X(W, 16, REV, true, STAGE, PERM) X(W, 17, REV, true, STAGE, PERM) X(W, 18, REV, true, STAGE, PERM) X(W, 19, REV, true, STAGE, PERM)   \
+    X(W, 20, REV, true, STAGE, PERM) X(W, 21, REV, true, STAGE, PERM) X(W, 22, REV, true, STAGE, PERM) X(W, 23, REV, true, STAGE, PERM)   \
+    X(W, 24, REV, true, STAGE, PERM) X(W, 25, REV, true, STAGE, PERM) X(W, 26, REV, true, STAGE, PERM) X(W, 27, REV, true, STAGE, PERM)   \
+    X(W, 28, REV, true, STAGE, PERM) X(W, 29, REV, true, STAGE, PERM) X(W, 30, REV, true, STAGE, PERM) X(W, 31, REV, true, STAGE, PERM)   \
+    X(W, 32, REV, true, STAGE, PERM)
+#define IPX_DP_DEFINE(W, S, REV, EX, STAGE, PERM) template __global__ void k_dp_pass<W, S, REV, EX, STAGE, PERM> IPX_DP_SIG;
+#define IPX_DP_EXTERN(W, S, REV, EX, STAGE, PERM) extern template __global__ void k_dp_pass<W, S, REV, EX, STAGE, PERM> IPX_DP_SIG;
+// every family the pipeline launches (ipx_launch_dp): translation unit, then what it holds
+#define IPX_DP_UNIT_A(X) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_LOW, true) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_LOW, false) X(16, IPX_MAX_SEG, false, false, IPX_STAGE_LOW, false)
+#define IPX_DP_UNIT_B(X) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_HIGH, true) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_EXACT, true)
+#define IPX_DP_UNIT_C(X) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_EXACT, false) X(16, IPX_MAX_SEG, false, false, IPX_STAGE_EXACT, false)
+#define IPX_DP_UNIT_D(X) IPX_DP_FAMILY(X, 16, true, IPX_STAGE_EXACT, true) IPX_DP_FAMILY(X, 16, true, IPX_STAGE_EXACT, false)              \
+    X(16, 16, true, false, IPX_STAGE_EXACT, false) X(16, 32, true, false, IPX_STAGE_EXACT, false) X(16, IPX_MAX_SEG, true, false, IPX_STAGE_EXACT, false)
+#define IPX_DP_UNIT_E(X) IPX_DP_FAMILY(X, 8, false, IPX_STAGE_EXACT, true)
+#define IPX_DP_UNIT_F(X) IPX_DP_FAMILY(X, 8, false, IPX_STAGE_EXACT, false) X(8, IPX_MAX_SEG, false, false, IPX_STAGE_EXACT, false)
+#define IPX_DP_UNIT_G(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, true)
+#define IPX_DP_UNIT_H(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, false)                                                                 \
+    X(8, 16, true, false, IPX_STAGE_EXACT, false) X(8, 32, true, false, IPX_STAGE_EXACT, false) X(8, IPX_MAX_SEG, true, false, IPX_STAGE_EXACT, false)
+#if defined(IPX_EXTERN_KERNELS)
+IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
+IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)
+#endif
+#endif

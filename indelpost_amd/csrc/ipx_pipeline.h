@@ -2,17 +2,21 @@
 // ssw.c:842-916, over a whole job table).  Written against a tiny launcher so the HIP runtime
 // (ipx_runtime.hip) and the test-only wave emulator (tests/emu) run the identical sequence.
 //
-//   init -> [plan + 8-bit forward] -> [plan + 16-bit forward for overflowed reads]
-//        -> [plan + 8-bit reverse] -> [plan + 16-bit reverse] -> traceback list -> banded traceback
+//   init -> [16-bit forward first + overflow proof, long reads] -> [8-bit forward: lower bound, upper bound, stepped]
+//        -> [16-bit forward for overflowed reads] -> [8-bit reverse] -> [16-bit reverse] -> traceback list -> banded traceback
 //
-// No host synchronisation happens between the stages: which job takes which branch is decided by
-// the planner kernels on the device.
+// No host synchronisation happens between the stages: which job takes which branch is decided on the device.  The
+// job lists of the two passes every job STARTS in depend only on host-known facts and are built once per resident
+// batch (ipx_build_static_plans); every other pass is counted by the kernels that send jobs into it and needs one
+// scatter launch (k_plan_scatter) on the stream.
 #pragma once
 #include <stdlib.h>
+#include <string.h>
 #include "ipx_kernels.h"
 
 struct IpxWorkspace {
-    IpxPlan plan;
+    IpxPlan plan[IPX_NUM_PASSES];
+    uint32_t *plan_tables;              // [IPX_NUM_PASSES][2][IPX_NUM_CLASSES]: count and cursor of every pass, the dynamic passes' part zeroed per run
     uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: 7 lists (first band 1..7) of n_jobs slots; 8 counters, the 8th = tb_esc_n
     uint32_t *tb_esc, *tb_esc_n;        // jobs the fast traceback hands to the general (one wave per job) kernel
     IpxTbScratch tb1;
@@ -22,30 +26,33 @@ struct IpxWorkspace {
 
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
+#define IPX_MAX_READ_LEN (8 * IPX_MAX_SEG)
 
+// what the host knows about a batch: which classes can occur in which pass
 struct IpxDims {
     int max_read_len;                  // longest read of the batch
     int max_ref_len;                   // longest window of the batch
-    uint8_t has8[IPX_NUM_CLASSES];     // segLen classes present among the reads, 8-bit pass
-    uint8_t has16[IPX_NUM_CLASSES];    // ... 16-bit pass
-    uint8_t any_slow_gap;              // some job has gap_open <= gap_ext
+    uint32_t lenhist[2][IPX_MAX_READ_LEN + 1];   // reads per length; [1] = jobs with gap_open <= gap_ext ("slow": stepped lazy-F)
+    // derived by ipx_dims_finish for the current scoring parameters: classes (segLen, + IPX_SLOW_BASE when slow) present
+    uint8_t has8_low[IPX_NUM_CLASSES], has8_wf[IPX_NUM_CLASSES];     // 8-bit classes of the reads that start in the 8-bit / in the 16-bit-first pass
+    uint8_t has16_low[IPX_NUM_CLASSES], has16_wf[IPX_NUM_CLASSES];   // 16-bit classes of the same two sets
+    uint8_t any_wf, any_low;
 };
 
-static inline void ipx_dims_add_read(IpxDims &d, int len)
+static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
 {
     if (len > d.max_read_len) d.max_read_len = len;
-    int c8 = (len + 15) / 16, c16 = (len + 7) / 8;
-    if (c8 > IPX_MAX_SEG) c8 = IPX_MAX_SEG;       // longer reads are refused by the planner (status bit)
-    if (c16 > IPX_MAX_SEG) c16 = IPX_MAX_SEG;
-    d.has8[c8] = 1;
-    d.has16[c16] = 1;
+    if (len > IPX_MAX_READ_LEN) len = IPX_MAX_READ_LEN;       // longer reads are refused (upload / planner status bit)
+    if (len < 0) len = 0;
+    ++d.lenhist[slow ? 1 : 0][len];
 }
 
 // kernel classes for per-kernel timing (ipx_runtime.hip records HIP events around each launch)
 enum {
-    IPX_K_INIT = 0, IPX_K_PLAN, IPX_K_BYTE_FWD, IPX_K_WORD_FWD, IPX_K_BYTE_REV, IPX_K_WORD_REV,
-    IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_BYTE_FWD_X, IPX_K_WORD_FIRST, IPX_K_PROVE, IPX_K_NUM
+    IPX_K_INIT = 0, IPX_K_PLAN, IPX_K_BYTE_LOW, IPX_K_BYTE_CHECK, IPX_K_BYTE_HIGH, IPX_K_BYTE_EXACT, IPX_K_WORD_FIRST, IPX_K_WORD_FWD,
+    IPX_K_BYTE_REV, IPX_K_WORD_REV, IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_PROVE, IPX_K_NUM
 };
+static inline bool ipx_k_is_dp(int kc) { return kc >= IPX_K_BYTE_LOW && kc <= IPX_K_WORD_REV; }
 
 // DP grid cap, in blocks (= waves) per CU.  Far more than are resident (<= 24): with several streams
 // sharing the GPU, short-lived blocks let the kernels of different streams interleave and even out the
@@ -53,53 +60,50 @@ enum {
 // Each block owns a column-maxima scratch region, so the grid is also capped by IPX_DP_SCRATCH_BUDGET.
 #define IPX_DP_WAVES_PER_CU 64
 #define IPX_DP_SCRATCH_BUDGET ((size_t)1 << 30)
-static inline int ipx_dp_grid_mult()
-{
-    static const int m = getenv("IPX_DP_GRID_MULT") ? atoi(getenv("IPX_DP_GRID_MULT")) : IPX_DP_WAVES_PER_CU;   // tuning experiments
-    return m > 0 ? m : IPX_DP_WAVES_PER_CU;
-}
 // column maxima of a forward selector-profile kernel stay in LDS while 16 waves per CU still fit (160 KB)
 #define IPX_DP_MC_LDS_MAX 10112
-static inline bool ipx_dp_mc_in_lds(int W, bool rev, int maxcols, bool perm)
+static inline bool ipx_dp_mc_in_lds(int W, bool rev, int maxcols, bool perm, int routing)
 {
-    return perm && !rev && (64 / W) * maxcols * 4 <= IPX_DP_MC_LDS_MAX && !getenv("IPX_NO_MC_LDS");
+    return perm && !rev && (64 / W) * maxcols * 4 <= IPX_DP_MC_LDS_MAX && !(routing & IPX_ROUTE_NO_MC_LDS);
 }
-static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm = false)
+static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm, int routing)
 {
-    static const int extra = getenv("IPX_DEBUG_EXTRA_LDS") ? atoi(getenv("IPX_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
-    const int mc = ipx_dp_mc_in_lds(W, rev, maxcols, perm) ? (64 / W) * maxcols * 4 : 0;
-    return (perm ? 64 : 640 * (SMAX > 0 ? SMAX : 1)) + 64 + mc + extra;
+    const int mc = ipx_dp_mc_in_lds(W, rev, maxcols, perm, routing) ? (64 / W) * maxcols * 4 : 0;
+    return (perm ? 64 : 640 * (SMAX > 0 ? SMAX : 1)) + 64 + mc;
 }
 
 // the register-selector profile (k_dp_pass PERM) needs a read letter N to score 0 against every window letter
-static inline bool ipx_perm_profile_ok(const int8_t *mat)
+static inline bool ipx_perm_profile_ok(const int8_t *mat, int routing)
 {
-    const bool off = getenv("IPX_NO_PERM_PROFILE") != nullptr;   // (looked up per launch: the tests flip it)
-    return !off && mat[4] == 0 && mat[9] == 0 && mat[14] == 0 && mat[19] == 0 && mat[24] == 0;
+    return !(routing & IPX_ROUTE_NO_PERM_PROFILE) && mat[4] == 0 && mat[9] == 0 && mat[14] == 0 && mat[19] == 0 && mat[24] == 0;
 }
 
-// timing key of a launch: kernel class * 128 + sub (DP kernels: sub = segLen, 65 = long-read kernel)
-#define IPX_KEY(kclass, sub) ((kclass) * 128 + (sub))
-#define IPX_NUM_KEYS (IPX_K_NUM * 128)
-#define IPX_SUB_GENERIC 65
+// timing key of a launch: kernel class * 256 + sub (DP kernels: sub = class, IPX_SUB_GENERIC = long-read / sweep kernel)
+#define IPX_KEY(kclass, sub) ((kclass) * 256 + (sub))
+#define IPX_NUM_KEYS (IPX_K_NUM * 256)
+#define IPX_SUB_GENERIC 140
 
-template <class BE, int W, bool REV, bool LOW>
-static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int S, int maxcols, int kclass, int pass)
+template <class BE, int W, bool REV, int STAGE>
+static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int cls, int maxcols, int kclass, int pass, int routing)
 {
+    const bool slow = cls >= IPX_SLOW_BASE;
+    const int S = slow ? cls - IPX_SLOW_BASE : cls;
+    // the selector-profile kernels of the 16-bit passes and of the 8-bit bracket stages have no stepped lazy-F loop
+    // (k_dp_pass, STEP): jobs with gap_open <= gap_ext are a class of their own and take the LDS-profile kernels
+    const bool perm = ipx_perm_profile_ok(b.mat, routing) && (!slow || (W == 16 && STAGE == IPX_STAGE_EXACT));
+    constexpr int NP_STAGE = STAGE == IPX_STAGE_HIGH ? IPX_STAGE_EXACT : STAGE;   // (the upper-bound stage exists in selector-profile form only)
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
         if (perm)                                                                                            \
-            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, true>, be.dp_grid(pass, N), 64,           \
-                      ipx_dp_lds_bytes(W, N, REV, maxcols, true), b, p, N, N, maxcols,                       \
-                      pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true) ? IPX_PASS_MC_LDS : 0), (uint64_t)0);  \
+            be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, STAGE, true>, be.dp_grid(pass, cls), 64,     \
+                      ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, cls, maxcols,          \
+                      pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0), (uint64_t)0, (uint64_t)0);  \
         else                                                                                                 \
-            be.launch(IPX_KEY(kclass, N), k_dp_pass<W, N, REV, true, LOW, false>, be.dp_grid(pass, N), 64,          \
-                      ipx_dp_lds_bytes(W, N, REV, maxcols), b, p, N, N, maxcols, pass, (uint64_t)0);         \
+            be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, NP_STAGE, false>, be.dp_grid(pass, cls), 64, \
+                      ipx_dp_lds_bytes(W, N, REV, maxcols, false, routing), b, p, cls, cls, maxcols, pass,   \
+                      (uint64_t)0, (uint64_t)0);                                                             \
         break;
-    // the selector-profile kernels of the 16-bit passes and of the 8-bit lower-bound stage have no stepped lazy-F
-    // loop (k_dp_pass, STEP): they are for batches in which every job has gap_open > gap_ext
-    const bool perm = ipx_perm_profile_ok(b.mat) && ((W == 16 && !LOW) || !b.any_slow_gap);
-    be.note_dp(IPX_KEY(kclass, S), pass, S, 128 / W);
+    be.note_dp(IPX_KEY(kclass, cls), pass, cls, 128 / W);
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
         IPX_DP_CASE(7) IPX_DP_CASE(8) IPX_DP_CASE(9) IPX_DP_CASE(10) IPX_DP_CASE(11) IPX_DP_CASE(12) IPX_DP_CASE(13)
@@ -111,92 +115,126 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 #undef IPX_DP_CASE
 }
 
-// Forward passes launch exactly the segLen classes that occur among the reads (known on the host).
+// Forward passes launch exactly the classes that can occur among their reads (known on the host).
 // Reverse passes align a read PREFIX whose length is only known on the device: almost always the
 // prefix has the read's own class or the one below, so those get their exact-segLen launch and ONE
 // branch-guarded launch sweeps up every other class (it skips the tiles the exact launches own).
-template <class BE, int W, bool REV, bool LOW>
-static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass)
+template <class BE, int W, bool REV, int STAGE>
+static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass, int routing)
 {
-    int top = -1;
-    for (int c = 0; c < IPX_NUM_CLASSES; ++c) if (has[c]) top = c;
-    if (top < 0) return;
-    uint64_t exact = 0;                                           // classes with their own launch
-    for (int c = 0; c <= top && c <= IPX_MAX_EXACT; ++c) {
-        const bool own = REV ? (has[c] || (c + 1 <= top && has[c + 1])) : has[c] != 0;
-        if (own) { exact |= 1ull << c; ipx_launch_dp_class<BE, W, REV, LOW>(be, b, p, c, maxcols, kclass, pass); }
-    }
+    uint64_t exact[2] = {0, 0};                                   // classes with their own launch: [0] fast, [1] slow gaps
     bool rest = false;                                            // anything the exact launches do not cover?
-    for (int c = 0; c <= top; ++c)
-        if ((REV || has[c]) && !(c < 64 && ((exact >> c) & 1ull))) rest = true;
+    int need = 0;                                                 // ... and its largest segLen
+    for (int half = 0; half < 2; ++half) {
+        const uint8_t *hs = has + half * IPX_SLOW_BASE;
+        int top = -1;
+        for (int c = 0; c <= IPX_MAX_SEG; ++c) if (hs[c]) top = c;
+        for (int c = 0; c <= top && c <= IPX_MAX_EXACT; ++c) {
+            const bool own = REV ? (hs[c] || (c + 1 <= top && hs[c + 1])) : hs[c] != 0;
+            if (own) { exact[half] |= 1ull << c; ipx_launch_dp_class<BE, W, REV, STAGE>(be, b, p, c + half * IPX_SLOW_BASE, maxcols, kclass, pass, routing); }
+        }
+        for (int c = 0; c <= top; ++c)
+            if ((REV || hs[c]) && !(c < 64 && ((exact[half] >> c) & 1ull))) { rest = true; need = c > need ? c : need; }
+    }
     if (!rest) return;
     // the sweep kernel keeps segLen registers for its largest class: size it for the largest class it
     // really has to serve (reverse passes: usually only short prefixes are left over), because the 64-segment
     // version needs a whole SIMD's register file per wave and queues behind everything else on a busy GPU
-    int need = 0;
-    for (int c = 0; c <= top; ++c)
-        if ((REV || has[c]) && !(c < 64 && ((exact >> c) & 1ull))) need = c;
-    if (REV && need <= 16)
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 16, REV, false, LOW>, be.sweep_grid(pass, exact, top), 64,
-                  ipx_dp_lds_bytes(W, 16, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
-    else if (REV && need <= 32)
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 32, REV, false, LOW>, be.sweep_grid(pass, exact, top), 64,
-                  ipx_dp_lds_bytes(W, 32, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
-    else
-        be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, LOW>, be.sweep_grid(pass, exact, top), 64,
-                  ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols), b, p, 0, top, maxcols, pass, exact);
+    constexpr int SW = STAGE == IPX_STAGE_HIGH ? IPX_STAGE_EXACT : STAGE;   // (8-bit classes never exceed 32 segments: no sweep in the bracket stages)
+    const int last = IPX_NUM_CLASSES - 1;
+    if constexpr (REV) {
+        if (need <= 16) {
+            be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 16, REV, false, SW>, be.sweep_grid(pass, exact[0], exact[1]), 64,
+                      ipx_dp_lds_bytes(W, 16, REV, maxcols, false, routing), b, p, 0, last, maxcols, pass, exact[0], exact[1]);
+            return;
+        }
+        if (need <= 32) {
+            be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, 32, REV, false, SW>, be.sweep_grid(pass, exact[0], exact[1]), 64,
+                      ipx_dp_lds_bytes(W, 32, REV, maxcols, false, routing), b, p, 0, last, maxcols, pass, exact[0], exact[1]);
+            return;
+        }
+    }
+    be.launch(IPX_KEY(kclass, IPX_SUB_GENERIC), k_dp_pass<W, IPX_MAX_SEG, REV, false, SW>, be.sweep_grid(pass, exact[0], exact[1]), 64,
+              ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols, false, routing), b, p, 0, last, maxcols, pass, exact[0], exact[1]);
+}
+
+// one scatter launch turns the counts of a pass (left by the kernels that sent jobs into it) into its job list;
+// count_first: the jobs come straight from their initial state, count them here
+template <class BE>
+static void ipx_plan_pass(BE &be, const IpxBatch &b, const IpxPlan &p, int pass, int na, bool count_first = false)
+{
+    if (count_first) be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, pass);
+    be.launch(IPX_KEY(IPX_K_PLAN, 1), k_plan_scatter, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass, na);
+}
+
+// count + cursor tables of pass `pass` inside IpxWorkspace::plan_tables
+static inline uint32_t *ipx_plan_count_of(uint32_t *tables, int pass) { return tables + (size_t)pass * 2 * IPX_NUM_CLASSES; }
+#define IPX_PLAN_TABLE_WORDS (IPX_NUM_PASSES * 2 * IPX_NUM_CLASSES)
+
+// The job lists of the passes a job starts in (every record PENDING): they depend on the read lengths, the penalties
+// and the scoring parameters only, so they are built when a batch (or the parameters) changed, not in every run.
+template <class BE>
+static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace &ws)
+{
+    be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
+    be.zero_u32(ipx_plan_count_of(ws.plan_tables, 0), IPX_FIRST_DYNAMIC_PASS * 2 * IPX_NUM_CLASSES);
+    if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, 16, true);
+    if (b.score_size != 1) ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW], IPX_PASS_BYTE_LOW, 8, true);
 }
 
 template <class BE>
-static void ipx_plan_pass(BE &be, const IpxBatch &b, const IpxPlan &p, int pass, int na)
+static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing)
 {
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_zero, 1, 128, 0, p);
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.flat_grid(b.n_jobs) * 256 / IPX_PLAN_BLOCK + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass);
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scan, 1, 64, 0, p, na, pass);
-    be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_scatter, be.flat_grid(b.n_jobs) * 256 / IPX_PLAN_BLOCK + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, p, pass);
-}
-
-template <class BE>
-static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d)
-{
-    int maxcols = d.max_ref_len + 4;
-    if (getenv("IPX_DEBUG_MAXCOLS")) maxcols = atoi(getenv("IPX_DEBUG_MAXCOLS"));   // timing experiments only (breaks score2)
+    const int maxcols = d.max_ref_len + 4;
+    uint8_t has8_all[IPX_NUM_CLASSES], has16_all[IPX_NUM_CLASSES];
+    for (int c = 0; c < IPX_NUM_CLASSES; ++c) { has8_all[c] = d.has8_low[c] | d.has8_wf[c]; has16_all[c] = d.has16_low[c] | d.has16_wf[c]; }
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(b.cigar_cursor, 1);
     be.zero_u32(ws.tb_list_n, 8);
+    be.zero_u32(ipx_plan_count_of(ws.plan_tables, IPX_FIRST_DYNAMIC_PASS), (IPX_NUM_PASSES - IPX_FIRST_DYNAMIC_PASS) * 2 * IPX_NUM_CLASSES);
 
-    if (b.score_size == 2 && b.word_first_len > 0 && d.max_read_len >= b.word_first_len) {
+    const bool wf = b.score_size == 2 && d.any_wf;
+    if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
-        ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_FIRST, 16);
-        ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST);
-        {
-            int cap = 64 * d.max_read_len;                        // one wave's reads
-            if (cap > 60 * 1024) cap = 60 * 1024;
-            be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, cap + 64, b, cap);
-        }
+        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
+        int cap = 64 * d.max_read_len;                            // one wave's reads
+        if (cap > 60 * 1024) cap = 60 * 1024;
+        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, cap + 64, b, cap);
     }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
-        ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD, 8);
-        ipx_launch_dp<BE, 16, false, true>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD, IPX_PASS_BYTE_FWD);
-        // reads whose lower-bound stage was inconclusive: exact 8-bit pass
-        ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_FWD_EXACT, 8);
-        ipx_launch_dp<BE, 16, false, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_FWD_X, IPX_PASS_BYTE_FWD_EXACT);
+        if (d.any_low)
+            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW], d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_LOW, routing);
+        if (wf) {                                                // word-first reads whose overflow could not be proven
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, 8);
+            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
+        }
+        if (b.use_bracket && d.any_low) {                        // upper-bound stage: certifies the lower-bound outputs or not
+            uint8_t hs[IPX_NUM_CLASSES];                          // (fast-gap classes only: a slow-gap read is stepped, never bracketed)
+            memset(hs, 0, sizeof hs);
+            memcpy(hs, d.has8_low, IPX_SLOW_BASE);
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_HIGH], IPX_PASS_BYTE_HIGH, 8);
+            ipx_launch_dp<BE, 16, false, IPX_STAGE_HIGH>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], hs, maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
+        }
+        // reads the bracket left open: the reference's stepped lazy-F
+        ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_EXACT], IPX_PASS_BYTE_EXACT, 8);
+        ipx_launch_dp<BE, 16, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_EXACT], has8_all, maxcols, IPX_K_BYTE_EXACT, IPX_PASS_BYTE_EXACT, routing);
     }
     if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
-        ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_FWD, 16);
-        ipx_launch_dp<BE, 8, false, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD);
+        ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, 16, b.score_size == 1);
+        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], b.score_size == 1 ? has16_all : d.has16_low, maxcols,
+                                                     IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing);
     }
     if (b.flag != 0) {                                           // begin position (ssw.c:872-886)
         if (b.score_size != 1) {
-            ipx_plan_pass(be, b, ws.plan, IPX_PASS_BYTE_REV, 8);
-            ipx_launch_dp<BE, 16, true, false>(be, b, ws.plan, d.has8, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV);
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
+            ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing);
         }
         if (b.score_size != 0) {
-            ipx_plan_pass(be, b, ws.plan, IPX_PASS_WORD_REV, 16);
-            ipx_launch_dp<BE, 8, true, false>(be, b, ws.plan, d.has16, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV);
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, 16);
+            ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
-            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.flat_grid(b.n_jobs) * 256 / IPX_PLAN_BLOCK + 1, IPX_PLAN_BLOCK, IPX_PLAN_LDS, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
+            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
             const int want = d.max_read_len > 0 ? d.max_read_len : 1;
             const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;
@@ -207,7 +245,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
               rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n);
             // small batch: all widths side by side in one launch (latency); large batch: one launch per width
             // (each width has its own register footprint and occupancy)
-            const int64_t fuse_max = getenv("IPX_TBF_FUSE_MAX") ? atoll(getenv("IPX_TBF_FUSE_MAX")) : 20000;
+            const int64_t fuse_max = (routing & IPX_ROUTE_TB_NO_FUSE) ? 0 : 20000;
             const int per_want = (int)((b.n_jobs + 63) / 64) + 1, per_have = ws.tbf_waves / 7;
             if (b.n_jobs <= fuse_max && per_have >= 1) {
                 const int per = per_want < per_have ? per_want : per_have;
@@ -239,13 +277,36 @@ static inline int ipx_word_first_len(const int8_t *mat, int bias)
     return (cap * 14 / 10 + mx - 1) / mx;
 }
 
-// shortest read that could overflow the 8-bit pass: len * max(mat) >= 255 - bias
-static inline int ipx_byte_safe_len(const int8_t *mat, int bias)
+// The bracket (lower + upper bound stage) costs two closed-form passes; the stepped pass costs one plus the stepping,
+// which grows with the number of columns whose carries sit in signed-compare territory (>= 128).  A read that can only
+// just get there (best possible score below ~1.25 x 128) has few such columns and is cheaper stepped (r02: config 2a,
+// 150 bp at match 1: 360 instructions per tile column stepped vs 2 x 194 bracketed; 75 bp at match 3: 745 vs 2 x 140).
+// Any value is correct; it only moves work between passes.
+static inline int ipx_bracket_min_len(const int8_t *mat)
 {
     int mx = 0;
     for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
     if (mx <= 0) return 0x7FFFFFFF;
-    return (255 - bias + mx - 1) / mx;
+    return (160 + mx - 1) / mx;
+}
+
+// which classes can occur in which pass, for the current scoring parameters (host-known facts only)
+static inline void ipx_dims_finish(IpxDims &d, int word_first_len, int score_size)
+{
+    memset(d.has8_low, 0, sizeof d.has8_low); memset(d.has8_wf, 0, sizeof d.has8_wf);
+    memset(d.has16_low, 0, sizeof d.has16_low); memset(d.has16_wf, 0, sizeof d.has16_wf);
+    d.any_wf = d.any_low = 0;
+    for (int slow = 0; slow < 2; ++slow)
+        for (int len = 0; len <= IPX_MAX_READ_LEN; ++len) {
+            if (!d.lenhist[slow][len]) continue;
+            int c8 = (len + 15) / 16, c16 = (len + 7) / 8;
+            if (c8 > IPX_MAX_SEG) c8 = IPX_MAX_SEG;
+            if (c16 > IPX_MAX_SEG) c16 = IPX_MAX_SEG;
+            const bool wfirst = score_size == 2 && word_first_len > 0 && len >= word_first_len;
+            (wfirst ? d.has8_wf : d.has8_low)[c8 + slow * IPX_SLOW_BASE] = 1;
+            (wfirst ? d.has16_wf : d.has16_low)[c16 + slow * IPX_SLOW_BASE] = 1;
+            if (wfirst) d.any_wf = 1; else d.any_low = 1;
+        }
 }
 
 // scratch sizing shared by both back-ends -------------------------------------------------------

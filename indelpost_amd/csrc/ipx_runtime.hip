@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/indelpost_hip.h"
+#define IPX_EXTERN_KERNELS 1      // the k_dp_pass families are instantiated in csrc/ipx_dp_*.hip
 #include "ipx_pipeline.h"
 
 static_assert(sizeof(IpxResult) == 32 && sizeof(ipx_result) == 32, "result record is 32 bytes");
@@ -58,6 +59,8 @@ struct ipx_ctx {
     // parameters
     int8_t mat[25];
     int bias = 0, flag = 1, filters = 0, filterd = 0, score_size = 2;
+    int routing = 0;                   // IPX_ROUTE_* (speed only)
+    bool static_valid = false;         // the job lists of the static passes match the resident batch and the parameters
     // resident batch
     int64_t n_jobs = 0;
     int32_t n_refs = 0;
@@ -65,7 +68,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_esc, tb1, maxcol, tbf;
+    DevBuf perm, tb_list, tb_esc, tb1, maxcol, tbf;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -78,11 +81,13 @@ struct ipx_ctx {
     float k_ms[IPX_NUM_KEYS];
     int k_launches[IPX_NUM_KEYS];
     int64_t k_units[IPX_NUM_KEYS];              // alignments the launches of a DP timing key processed (planner tile counts x tile size)
-    int32_t k_dp_src[IPX_NUM_KEYS];             // DP timing key -> (pass * 128 + class) * 32 + alignments per tile, or -1
+    int32_t k_dp_src[IPX_NUM_KEYS];             // DP timing key -> (pass * 256 + class) * 32 + alignments per tile, or -1
+    int runs_since_sync = 0;                    // ipx_run calls the next ipx_sync accounts for (same batch: same tile counts each)
     hipEvent_t run_start = nullptr, run_stop = nullptr;
     float last_run_ms = 0.f;
     int64_t dp_grid_cap = 1;                    // DP blocks per launch (each owns a column-maxima scratch region)
     uint32_t prev_tiles[IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1)] = {0};   // planner tile counts of the previous run, per pass and class
+    uint32_t *stats_dev = nullptr;              // ... and where the planner leaves them
     bool prev_valid = false;
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
 };
@@ -110,13 +115,24 @@ struct HipBackend {
         return (int)(g < full ? g : full);
     }
     int dp_grid(int pass, int cls) const { return sized(c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + cls]); }
-    int sweep_grid(int pass, uint64_t covered, int top) const
+    int sweep_grid(int pass, uint64_t covered_fast, uint64_t covered_slow) const
     {
         int64_t t = 0;
-        for (int k = 0; k <= top && k < IPX_NUM_CLASSES; ++k)
-            if (!(k < 64 && ((covered >> k) & 1ull))) t += c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + k];
+        for (int k = 0; k < IPX_NUM_CLASSES; ++k) {
+            const int seg = k >= IPX_SLOW_BASE ? k - IPX_SLOW_BASE : k;
+            const uint64_t cov = k >= IPX_SLOW_BASE ? covered_slow : covered_fast;
+            if (!(seg < 64 && ((cov >> seg) & 1ull))) t += c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + k];
+        }
         const int64_t g = sized(t), cap = (int64_t)c->num_cu * 8;
         return (int)(c->prev_valid ? g : (g < cap ? g : cap));
+    }
+    // planner kernels: one wave per block, four jobs per lane
+    int plan_grid(int64_t n) const
+    {
+        int64_t g = (n + 255) / 256;
+        if (g < 1) g = 1;
+        const int64_t cap = (int64_t)c->num_cu * 16;
+        return (int)(g < cap ? g : cap);
     }
     int flat_grid(int64_t n) const
     {
@@ -125,7 +141,7 @@ struct HipBackend {
         const int64_t cap = (int64_t)c->num_cu * 8;
         return (int)(g < cap ? g : cap);
     }
-    void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 128 + cls) * 32 + na; }
+    void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 256 + cls) * 32 + na; }
     void zero_u32(uint32_t *p, int n)
     {
         hipError_t e = hipMemsetAsync(p, 0, sizeof(uint32_t) * (size_t)n, c->stream);
@@ -146,9 +162,8 @@ struct HipBackend {
         size_t ei = 0;
         // profiling level 2 = only the striped DP kernels get events (they are the step; events around all ~75
         // launches of a run cost about 1.5 % of a 4-stream step)
-        const int kc = kclass / 128;
-        const bool timed = c->profiling && (c->profiling_level < 2 || (kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) ||
-                                            kc == IPX_K_BYTE_FWD_X || kc == IPX_K_WORD_FIRST);
+        const int kc = kclass / 256;
+        const bool timed = c->profiling && (c->profiling_level < 2 || ipx_k_is_dp(kc));
         if (timed) {
             if (c->ev_next + 2 > c->ev_pool.size()) {
                 for (int k = 0; k < 64; ++k) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
@@ -167,8 +182,8 @@ struct HipBackend {
     }
 };
 
-static const char *k_names[IPX_K_NUM] = {"init", "plan", "dp_byte_fwd", "dp_word_fwd", "dp_byte_rev",
-                                         "dp_word_rev", "tb_list", "traceback", "pack_refs", "dp_byte_fwd_exact", "dp_word_first", "prove_overflow"};
+static const char *k_names[IPX_K_NUM] = {"init", "plan", "dp_byte_low", "dp_byte_check", "dp_byte_high", "dp_byte_exact", "dp_word_first",
+                                         "dp_word_fwd", "dp_byte_rev", "dp_word_rev", "tb_list", "traceback", "pack_refs", "prove_overflow"};
 
 extern "C" {
 
@@ -233,6 +248,15 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
     for (int k = 0; k < 25; ++k) if (mat[k] < bias) bias = mat[k];          // ssw.c:795-797
     c->bias = -bias;
     c->flag = flag & 255; c->filters = filters & 0xFFFF; c->filterd = filterd; c->score_size = score_size;
+    c->static_valid = false;
+    return IPX_OK;
+}
+
+int ipx_set_routing(ipx_ctx *c, int flags)
+{
+    if (!c) { set_err("ipx_set_routing: null context"); return IPX_ERR_ARG; }
+    c->routing = flags;
+    c->static_valid = false;
     return IPX_OK;
 }
 
@@ -250,8 +274,9 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     // host-side geometry: packed (4-byte aligned, padded) window offsets and the batch maxima
     std::vector<int64_t> refp((size_t)n_refs + 1);
     std::vector<int32_t> rlen((size_t)n_refs + 1);
-    IpxDims d;
+    IpxDims &d = c->dims;
     memset(&d, 0, sizeof d);
+    c->static_valid = false;
     int64_t tot = 0;
     for (int32_t r = 0; r < n_refs; ++r) {
         const int64_t len = ref_off[r + 1] - ref_off[r];
@@ -263,13 +288,12 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     for (int64_t i = 0; i < n_jobs; ++i) {
         const int64_t len = read_off[i + 1] - read_off[i];
         if (len < 0 || len > 8 * IPX_MAX_SEG) { set_err("read %lld has length %lld (limit %d)", (long long)i, (long long)len, 8 * IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
-        ipx_dims_add_read(d, (int)len);
-        if (gap_open[i] <= gap_ext[i]) d.any_slow_gap = 1;
+        ipx_dims_add_read(d, (int)len, gap_open[i] <= gap_ext[i]);
         if (ref_id[i] < 0 || ref_id[i] >= n_refs) { set_err("job %lld: ref_id %d out of range", (long long)i, ref_id[i]); return IPX_ERR_ARG; }
     }
     // launch sizes learned from the previous run only carry over to a batch of similar size
     if (c->prev_valid && (n_jobs > 2 * c->n_jobs || 2 * n_jobs < c->n_jobs)) c->prev_valid = false;
-    c->n_jobs = n_jobs; c->n_refs = n_refs; c->dims = d; c->have_mask = mask_len != nullptr;
+    c->n_jobs = n_jobs; c->n_refs = n_refs; c->have_mask = mask_len != nullptr;
 
     if (c->reads.ensure((size_t)read_bytes + 64) || c->read_off.ensure(8 * ((size_t)n_jobs + 1)) ||
         c->refs_raw.ensure((size_t)ref_bytes + 64) || c->ref_off.ensure(8 * ((size_t)n_refs + 1)) ||
@@ -277,8 +301,9 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         c->ref_len.ensure(4 * ((size_t)n_refs + 1)) || c->ref_id.ensure(4 * (size_t)n_jobs + 4) ||
         c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
-        c->perm.ensure(4 * (size_t)n_jobs + 4) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
-        c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->small.ensure(4096))
+        c->perm.ensure(12 * (size_t)n_jobs + 16) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
+        c->tb_esc.ensure(4 * (size_t)n_jobs + 4) ||
+        c->small.ensure(4 * ((size_t)IPX_PLAN_TABLE_WORDS + (size_t)IPX_NUM_PASSES * 3 * (IPX_NUM_CLASSES + 1) + 64)))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
     if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
@@ -322,8 +347,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         if (c->tbf.ensure(ipx_tbf_scratch_bytes_per_block(rowcap) * (size_t)wf + 64)) return IPX_ERR_NO_DEVICE;
         c->ws.tbf_scratch = c->tbf.as<unsigned char>();
     }
-    static const int tb1_mult = getenv("IPX_TB1_MULT") ? atoi(getenv("IPX_TB1_MULT")) : 16;
-    int w1 = c->num_cu * (tb1_mult > 0 ? tb1_mult : 16);      // one job per block in k_tb_coop (latency-bound: many blocks)
+    int w1 = c->num_cu * 16;                                  // one job per block in k_tb_coop (latency-bound: many blocks)
     const size_t lim1 = 1024ull << 20;
     while (w1 > 1 && ipx_tbc_bytes_per_block(s1) * (size_t)w1 > lim1) w1 /= 2;
     c->ws.tb1_waves = w1;
@@ -336,28 +360,34 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     // column-maxima scratch of the forward passes: one region per DP block
     {
         const size_t per_block = 16 * (size_t)(d.max_ref_len + 8) * 4;
-        int64_t cap = (int64_t)c->num_cu * ipx_dp_grid_mult();
+        int64_t cap = (int64_t)c->num_cu * IPX_DP_WAVES_PER_CU;
         const int64_t fit = (int64_t)(IPX_DP_SCRATCH_BUDGET / per_block), floor_ = (int64_t)c->num_cu * 24;   // never below the resident count
         if (cap > fit) cap = fit > floor_ ? fit : floor_;
         c->dp_grid_cap = cap;
         if (c->maxcol.ensure((size_t)cap * per_block)) return IPX_ERR_NO_DEVICE;
     }
 
-    // small tables
+    // small tables: count + cursor of every pass, class and tile offsets of every pass, planner statistics
     uint32_t *sm = c->small.as<uint32_t>();
-    c->ws.plan.count = sm; sm += 128;
-    c->ws.plan.cursor = sm; sm += 128;
-    c->ws.plan.cls_off = sm; sm += 128;
-    c->ws.plan.tile_off = sm; sm += 128;
-    c->ws.plan.max_cols = nullptr;
-    c->ws.plan.stats = sm; sm += IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1);
-    c->ws.plan.perm = c->perm.as<uint32_t>();
+    c->ws.plan_tables = sm; sm += IPX_PLAN_TABLE_WORDS;
+    uint32_t *offs = sm; sm += (size_t)IPX_NUM_PASSES * 2 * (IPX_NUM_CLASSES + 1);
+    c->stats_dev = sm; sm += (size_t)IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1);
+    for (int ps = 0; ps < IPX_NUM_PASSES; ++ps) {
+        IpxPlan &p = c->ws.plan[ps];
+        p.count = ipx_plan_count_of(c->ws.plan_tables, ps);
+        p.cursor = p.count + IPX_NUM_CLASSES;
+        p.cls_off = offs + (size_t)ps * 2 * (IPX_NUM_CLASSES + 1);
+        p.tile_off = p.cls_off + IPX_NUM_CLASSES + 1;
+        p.perm = c->perm.as<uint32_t>() + (size_t)(ps < IPX_FIRST_DYNAMIC_PASS ? ps : IPX_FIRST_DYNAMIC_PASS) * (size_t)n_jobs;
+        p.stats = c->stats_dev + (size_t)ps * (IPX_NUM_CLASSES + 1);
+    }
     c->ws.tb_list = c->tb_list.as<uint32_t>();
     c->ws.tb_esc = c->tb_esc.as<uint32_t>();
     c->ws.tb_list_n = sm; sm += 8;
     c->ws.tb_esc_n = c->ws.tb_list_n + 7;
     uint32_t *cursor = sm; sm += 4;
     uint32_t *status = sm; sm += 4;
+    HIPCHK(hipMemsetAsync(c->small.p, 0, 4 * (size_t)(sm - c->small.as<uint32_t>()), s));
 
     IpxBatch &b = c->batch;
     memset(&b, 0, sizeof b);
@@ -370,6 +400,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     b.res = c->res.as<IpxResult>();
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
     b.cigar_cursor = cursor; b.status = status;
+    b.plan_counts = c->ws.plan_tables;
     b.maxcol_scratch = c->maxcol.as<uint32_t>();
     HIPCHK(hipStreamSynchronize(s));
     return IPX_OK;
@@ -381,16 +412,26 @@ int ipx_run(ipx_ctx *c)
     HIPCHK(hipSetDevice(c->device));
     IpxBatch &b = c->batch;
     memcpy(b.mat, c->mat, 25);
-    b.word_first_len = getenv("IPX_NO_WORD_FIRST") ? 0 : ipx_word_first_len(c->mat, c->bias);
-    b.byte_safe_len = getenv("IPX_NO_BYTE_SAFE") ? 0 : ipx_byte_safe_len(c->mat, c->bias);
+    b.word_first_len = (c->routing & IPX_ROUTE_NO_WORD_FIRST) ? 0 : ipx_word_first_len(c->mat, c->bias);
+    b.use_bracket = ipx_perm_profile_ok(c->mat, c->routing) && !(c->routing & IPX_ROUTE_NO_BRACKET);
+    b.bracket_min_len = ipx_bracket_min_len(c->mat);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
-    b.any_slow_gap = c->dims.any_slow_gap;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
     HipBackend be{c};
-    HIPCHK(hipEventRecord(c->run_start, c->stream));
     be.zero_u32(b.status, 1);
-    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims);
+    if (!c->static_valid && c->n_jobs > 0) {
+        // first run of this batch under these parameters: the job lists of the passes every job starts in
+        ipx_dims_finish(c->dims, b.word_first_len, c->score_size);
+        const bool prof = c->profiling;
+        c->profiling = false;
+        ipx_build_static_plans(be, b, c->ws);
+        c->profiling = prof;
+        c->static_valid = true;
+    }
+    HIPCHK(hipEventRecord(c->run_start, c->stream));
+    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims, c->routing);
+    ++c->runs_since_sync;
     HIPCHK(hipEventRecord(c->run_stop, c->stream));
     if (be.err != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }
     return IPX_OK;
@@ -413,19 +454,20 @@ int ipx_sync(ipx_ctx *c)
         c->ev_used.clear();
         c->ev_next = 0;
     }
-    if (c->n_jobs == 0) return IPX_OK;
+    if (c->n_jobs == 0) { c->runs_since_sync = 0; return IPX_OK; }
     uint32_t st = 0;
     HIPCHK(hipMemcpy(&st, c->batch.status, 4, hipMemcpyDeviceToHost));
-    if (c->ws.plan.stats && !getenv("IPX_NO_ADAPTIVE_GRID")) {
-        HIPCHK(hipMemcpy(c->prev_tiles, c->ws.plan.stats, sizeof c->prev_tiles, hipMemcpyDeviceToHost));
+    if (c->stats_dev) {
+        HIPCHK(hipMemcpy(c->prev_tiles, c->stats_dev, sizeof c->prev_tiles, hipMemcpyDeviceToHost));
         c->prev_valid = true;
         if (c->profiling)
             for (int k = 0; k < IPX_NUM_KEYS; ++k)
                 if (c->k_dp_src[k] >= 0) {
                     const int na = c->k_dp_src[k] & 31, pc = c->k_dp_src[k] >> 5;
-                    c->k_units[k] += (int64_t)c->prev_tiles[(pc >> 7) * (IPX_NUM_CLASSES + 1) + (pc & 127)] * na;
+                    c->k_units[k] += (int64_t)c->prev_tiles[(pc >> 8) * (IPX_NUM_CLASSES + 1) + (pc & 255)] * na * c->runs_since_sync;
                 }
     }
+    c->runs_since_sync = 0;
     if (st & IPX_STATUS_READ_TOO_LONG) { set_err("a read needs more than %d striped segments", IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
     if (st & IPX_STATUS_REF_TOO_LONG) { set_err("a window is longer than %d", IPX_MAX_REFLEN); return IPX_ERR_REF_TOO_LONG; }
     if (st & IPX_STATUS_CIGAR_POOL) { set_err("device cigar pool exhausted (%u ops)", c->cigar_cap); return IPX_ERR_CIGAR_POOL; }
@@ -488,9 +530,10 @@ const char *ipx_kernel_class_name(int k)
     // key = kernel class * 128 + sub; DP kernels are named after their segLen instantiation
     static thread_local char buf[64];
     if (k < 0 || k >= IPX_NUM_KEYS) return "";
-    const int kc = k / 128, sub = k % 128;
-    if ((kc >= IPX_K_BYTE_FWD && kc <= IPX_K_WORD_REV) || kc == IPX_K_BYTE_FWD_X || kc == IPX_K_WORD_FIRST) {
+    const int kc = k / 256, sub = k % 256;
+    if (ipx_k_is_dp(kc)) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
+        else if (sub >= IPX_SLOW_BASE) snprintf(buf, sizeof buf, "%s_slowgap_s%d", k_names[kc], sub - IPX_SLOW_BASE);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
     } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
     else snprintf(buf, sizeof buf, "%s", k_names[kc]);

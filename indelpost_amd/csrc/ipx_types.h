@@ -25,26 +25,48 @@ enum {
     IPX_MODE_WORD = 1,       // 8-bit pass overflowed (score 255), 16-bit pass used (ssw.c:844-847)
     IPX_MODE_FAIL = 2,       // reference would return NULL (8-bit only profile overflowed, ssw.c:848-851)
     IPX_MODE_NEED_WORD = 3,  // 8-bit pass overflowed, 16-bit pass still to run
-    IPX_MODE_NEED_BYTE_EXACT = 4,  // 8-bit lower-bound stage inconclusive, exact 8-bit pass still to run
+    IPX_MODE_NEED_BYTE_EXACT = 4,  // 8-bit bracket inconclusive, exact (stepped) 8-bit pass still to run
     IPX_MODE_WORD_UNPROVEN = 5,    // 16-bit result computed FIRST; 8-bit overflow not yet established
     IPX_MODE_NEED_BYTE_CHECK = 6,  // ... and not provable from the diagonal: the 8-bit pass decides
     IPX_MODE_NEED_BYTE_EXACT_W = 7,// as NEED_BYTE_EXACT, with a 16-bit result already in the record
+    IPX_MODE_NEED_BYTE_HIGH = 8,   // the record holds the LOWER-bound stage's outputs; the upper-bound stage certifies them or not
     IPX_MODE_PENDING = 255,  // not processed yet
 };
 
+// Passes of the pipeline.  A pass is a job list bucketed by class (= striped segment count, + IPX_SLOW_BASE for jobs with
+// gap_open <= gap_ext, which need kernels with the stepped lazy-F loop).  STATIC passes depend only on host-known facts
+// (read lengths, penalties, scoring parameters): their lists are built once per resident batch.  The lists of the other
+// passes are decided on the device: the kernel that decides a job's next pass also counts it (k_dp_pass finalisation,
+// k_prove_overflow), so that one scatter launch per pass is all the planning left on the stream.
 enum {
-    IPX_PASS_BYTE_FWD = 0,
-    IPX_PASS_WORD_FWD = 1,
-    IPX_PASS_BYTE_REV = 2,
-    IPX_PASS_WORD_REV = 3,
-    IPX_PASS_BYTE_FWD_EXACT = 4,
-    IPX_PASS_WORD_FIRST = 5,      // 16-bit forward pass BEFORE the 8-bit one, for reads that will almost surely overflow
-    IPX_NUM_PASSES = 6,
+    IPX_PASS_WORD_FIRST = 0,      // static: 16-bit forward pass BEFORE the 8-bit one, for reads that will almost surely overflow
+    IPX_PASS_BYTE_LOW = 1,        // static: 8-bit forward pass, lower-bound stage, every other read
+    IPX_PASS_BYTE_CHECK = 2,      // 8-bit lower-bound stage for word-first reads whose overflow could not be proven
+    IPX_PASS_BYTE_HIGH = 3,       // 8-bit forward pass, upper-bound stage: certifies the lower-bound outputs
+    IPX_PASS_BYTE_EXACT = 4,      // 8-bit forward pass with the reference's stepped lazy-F, for what the bracket left open
+    IPX_PASS_WORD_FWD = 5,        // 16-bit forward pass after an 8-bit overflow (ssw.c:844-847)
+    IPX_PASS_BYTE_REV = 6,
+    IPX_PASS_WORD_REV = 7,
+    IPX_NUM_PASSES = 8,
+    IPX_FIRST_DYNAMIC_PASS = 2,
     IPX_PASS_MC_LDS = 0x100,      // flag or-ed into a DP kernel's `pass` argument: column maxima live in LDS (room reserved by the launch)
 };
 
+// stage of an 8-bit forward kernel (template parameter of k_dp_pass)
+enum { IPX_STAGE_EXACT = 0, IPX_STAGE_LOW = 1, IPX_STAGE_HIGH = 2 };
+
+// speed-only routing switches (ipx_set_routing): every combination must give identical results, the tests run them all
+enum {
+    IPX_ROUTE_NO_WORD_FIRST = 1,   // never run the 16-bit pass before the 8-bit one
+    IPX_ROUTE_NO_PERM_PROFILE = 2, // LDS-staged int8 profile instead of the register selectors
+    IPX_ROUTE_NO_BRACKET = 4,      // no upper-bound stage: a read the lower-bound stage cannot settle goes to the stepped pass
+    IPX_ROUTE_TB_NO_FUSE = 8,      // one traceback launch per band width even for small batches
+    IPX_ROUTE_NO_MC_LDS = 16,      // column maxima in the global scratch even when they would fit in LDS
+};
+
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels
-#define IPX_NUM_CLASSES (IPX_MAX_SEG + 1)
+#define IPX_SLOW_BASE (IPX_MAX_SEG + 1)      // class of a job with gap_open <= gap_ext: segLen + IPX_SLOW_BASE
+#define IPX_NUM_CLASSES (2 * IPX_SLOW_BASE)
 #define IPX_MAX_REFLEN 4096  // column maxima are staged in LDS
 #define IPX_REF_PAD 8        // window starts are 4-byte aligned, with >= 4 readable bytes after the end
 
@@ -64,31 +86,33 @@ struct IpxBatch {
     int8_t mat[25];             // 5x5 substitution matrix (sswpy.pyx:306-336)
     int32_t bias;               // |min(mat)| (ssw.c:795-799)
     int32_t word_first_len;     // reads at least this long take the 16-bit pass first (0 = never); speed only
-    int32_t byte_safe_len;      // reads shorter than this cannot reach 255-bias (len * max(mat) < 255-bias): they skip the
-                                //   lower-bound stage of the 8-bit pass, whose only gain is a cheap overflow verdict; speed only
+    int32_t bracket_min_len;    // reads at least this long take the lower/upper-bound bracket when the lower-bound stage cannot
+                                //   settle them, shorter ones (few columns with big carries) the stepped pass directly; speed only
+    uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)
-    uint8_t any_slow_gap;       // some job has gap_open <= gap_ext (its lazy-F has to be stepped): chooses kernel variants
     uint16_t filters;
     int32_t filterd;
     IpxResult *res;             // n_jobs
     uint32_t *cigar_pool;
     uint32_t cigar_cap;         // capacity of cigar_pool in ops
     uint32_t *cigar_cursor;     // bump allocator (1 word)
+    uint32_t *plan_counts;      // jobs per pass and class: row `pass` starts at plan_counts + pass * 2 * IPX_NUM_CLASSES (the pass's
+                                //   scatter cursors follow its counts); the rows of the dynamic passes are zeroed at the start of a
+                                //   run and filled by the kernels that decide a job's next pass
     uint32_t *maxcol_scratch;   // per DP block: column maxima of the tile in flight (forward passes)
     uint32_t *status;           // bit0: cigar pool exhausted, bit1: read too long, bit2: ref too long, bit3: traceback scratch exhausted
 };
 
-// Planner output for one pass: jobs bucketed by segLen class.
+// Planner output for one pass: jobs bucketed by class.
 struct IpxPlan {
-    uint32_t *count;      // [IPX_NUM_CLASSES] jobs per class
+    uint32_t *count;      // [IPX_NUM_CLASSES] jobs per class (a row of IpxBatch::plan_counts)
     uint32_t *cursor;     // [IPX_NUM_CLASSES] scatter cursors
     uint32_t *cls_off;    // [IPX_NUM_CLASSES+1] first slot of class in perm
     uint32_t *tile_off;   // [IPX_NUM_CLASSES+1] first tile of class
     uint32_t *perm;       // [n_jobs] job ids grouped by class
-    uint32_t *max_cols;   // [IPX_NUM_CLASSES] longest column count in the class (sizes the LDS stage)
-    uint32_t *stats;      // [IPX_NUM_PASSES][IPX_NUM_CLASSES+1] tiles per class of the last plan of each pass (last entry: all
-                          //   classes); read back by the host after a run to size the next run's launches (speed only)
+    uint32_t *stats;      // [IPX_NUM_CLASSES+1] tiles per class of this pass's last plan (last entry: all classes); read back
+                          //   by the host after a run to size the next run's launches (speed only); may be null
 };
 
 enum {

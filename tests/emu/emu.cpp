@@ -165,8 +165,9 @@ struct EmuBackend {
     EmuBackend() { memset(launches, 0, sizeof launches); }
     int dp_grid() const { return 3; }
     int dp_grid(int, int) const { return 3; }
-    int sweep_grid(int, uint64_t, int) const { return 2; }
+    int sweep_grid(int, uint64_t, uint64_t) const { return 2; }
     int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
+    int plan_grid(int64_t n) const { return n > 100 ? 3 : 1; }
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
     void note_dp(int, int, int, int) {}
     template <class K, class... A>
@@ -181,19 +182,21 @@ struct EmuBackend {
 
 template <class T> static T *zalloc(size_t n) { return (T *)calloc(n ? n : 1, sizeof(T)); }
 
-// C entry used by tests/emu_backend.py: same arguments as ipx_align_batch (include/indelpost_hip.h)
+// C entry used by tests/emu_backend.py: same arguments as ipx_align_batch (include/indelpost_hip.h) plus the
+// scoring / routing parameters the HIP context holds; launches_out (optional): launches per timing key;
+// pass_jobs_out (optional): jobs that went through each of the IPX_NUM_PASSES passes
 extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, const int8_t *refs,
                                const int64_t *ref_off, const int32_t *ref_id, const uint8_t *gap_open,
                                const uint8_t *gap_ext, const int32_t *mask_len, const int8_t *mat,
                                int64_t n_jobs, int32_t n_refs, int flag, int filters, int filterd,
-                               int score_size, IpxResult *out, uint32_t *cigar_pool, uint32_t cigar_cap,
-                               uint32_t *status_out)
+                               int score_size, int routing, IpxResult *out, uint32_t *cigar_pool, uint32_t cigar_cap,
+                               uint32_t *status_out, int32_t *launches_out, uint32_t *pass_jobs_out)
 {
     EmuBackend be;
     IpxBatch b;
     memset(&b, 0, sizeof b);
-    IpxDims d;
-    memset(&d, 0, sizeof d);
+    IpxDims *dp = zalloc<IpxDims>(1);
+    IpxDims &d = *dp;
     std::vector<int64_t> refp_off((size_t)n_refs + 1);
     std::vector<int32_t> ref_len((size_t)n_refs + 1);
     int64_t tot = 0;
@@ -204,10 +207,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
         tot += ((len + 3) & ~3) + IPX_REF_PAD;
         if (len > d.max_ref_len) d.max_ref_len = len;
     }
-    for (int64_t i = 0; i < n_jobs; ++i) {
-        ipx_dims_add_read(d, (int)(read_off[i + 1] - read_off[i]));
-        if (gap_open[i] <= gap_ext[i]) d.any_slow_gap = 1;
-    }
+    for (int64_t i = 0; i < n_jobs; ++i) ipx_dims_add_read(d, (int)(read_off[i + 1] - read_off[i]), gap_open[i] <= gap_ext[i]);
     int8_t *packed = zalloc<int8_t>((size_t)tot + 64);
     be.launch(IPX_KEY(IPX_K_PACK, 0), k_pack_refs, 2, 256, 0, refs, ref_off, (const int64_t *)refp_off.data(), packed, n_refs);
 
@@ -215,26 +215,35 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.n_jobs = n_jobs; b.n_refs = n_refs; b.reads = reads; b.read_off = read_off;
     b.refs_packed = packed; b.refp_off = refp_off.data(); b.ref_len = ref_len.data(); b.ref_id = ref_id;
     b.gap_open = gap_open; b.gap_ext = gap_ext; b.mask_len = mask_len;
-    b.any_slow_gap = d.any_slow_gap;
     memcpy(b.mat, mat, 25);
     int bias = 0;
     for (int k = 0; k < 25; ++k) if (mat[k] < bias) bias = mat[k];
     b.bias = -bias;
-    b.word_first_len = getenv("IPX_NO_WORD_FIRST") ? 0 : ipx_word_first_len(mat, -bias);
-    b.byte_safe_len = getenv("IPX_NO_BYTE_SAFE") ? 0 : ipx_byte_safe_len(mat, -bias);
+    b.word_first_len = (routing & IPX_ROUTE_NO_WORD_FIRST) ? 0 : ipx_word_first_len(mat, -bias);
+    b.use_bracket = ipx_perm_profile_ok(mat, routing) && !(routing & IPX_ROUTE_NO_BRACKET);
+    b.bracket_min_len = getenv("IPX_EMU_BRACKET_ALWAYS") ? 0 : ipx_bracket_min_len(mat);
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
+    ipx_dims_finish(d, b.word_first_len, score_size);
 
     b.maxcol_scratch = zalloc<uint32_t>((size_t)be.dp_grid() * 16 * (size_t)(d.max_ref_len + 8));
     IpxWorkspace ws;
     memset(&ws, 0, sizeof ws);
-    ws.plan.count = zalloc<uint32_t>(IPX_NUM_CLASSES);
-    ws.plan.cursor = zalloc<uint32_t>(IPX_NUM_CLASSES);
-    ws.plan.cls_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
-    ws.plan.tile_off = zalloc<uint32_t>(IPX_NUM_CLASSES + 1);
-    ws.plan.perm = zalloc<uint32_t>((size_t)n_jobs);
-    ws.plan.max_cols = nullptr;
-    ws.plan.stats = nullptr;
+    ws.plan_tables = zalloc<uint32_t>(IPX_PLAN_TABLE_WORDS);
+    b.plan_counts = nullptr;
+    uint32_t *offs = zalloc<uint32_t>((size_t)IPX_NUM_PASSES * 2 * (IPX_NUM_CLASSES + 1));
+    uint32_t *perms = zalloc<uint32_t>(3 * (size_t)n_jobs);      // two static passes + one shared by the dynamic ones
+    for (int ps = 0; ps < IPX_NUM_PASSES; ++ps) {
+        IpxPlan &p = ws.plan[ps];
+        p.count = ipx_plan_count_of(ws.plan_tables, ps);
+        p.cursor = p.count + IPX_NUM_CLASSES;
+        p.cls_off = offs + (size_t)ps * 2 * (IPX_NUM_CLASSES + 1);
+        p.tile_off = p.cls_off + IPX_NUM_CLASSES + 1;
+        p.perm = perms + (size_t)(ps < IPX_FIRST_DYNAMIC_PASS ? ps : IPX_FIRST_DYNAMIC_PASS) * (size_t)n_jobs;
+        p.stats = nullptr;
+    }
+    // plan_counts[pass][class]: the count rows of plan_tables have a stride of 2 * IPX_NUM_CLASSES
+    b.plan_counts = ws.plan_tables;
     ws.tb_list = zalloc<uint32_t>(7 * (size_t)n_jobs);
     ws.tb_esc = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc_n = nullptr;
@@ -251,13 +260,26 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.tb1.cig = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)s1.cigcap * ws.tb1_waves + 64);
     memset(ws.tb1.dir, 0x5A, (size_t)s1.dircap * ws.tb1_waves);
 
-    ipx_run_pipeline(be, b, ws, d);
+    if (n_jobs > 0) {
+        ipx_build_static_plans(be, b, ws);
+        ipx_run_pipeline(be, b, ws, d, routing);
+    }
 
     *status_out = status;
+    if (launches_out) for (int k = 0; k < IPX_NUM_KEYS; ++k) launches_out[k] = be.launches[k];
+    if (pass_jobs_out)
+        for (int ps = 0; ps < IPX_NUM_PASSES; ++ps) {
+            pass_jobs_out[ps] = 0;
+            for (int c = 0; c < IPX_NUM_CLASSES; ++c) pass_jobs_out[ps] += ipx_plan_count_of(ws.plan_tables, ps)[c];
+        }
     free(packed);
     free(b.maxcol_scratch);
-    free(ws.plan.count); free(ws.plan.cursor); free(ws.plan.cls_off); free(ws.plan.tile_off); free(ws.plan.perm);
+    free(ws.plan_tables); free(offs); free(perms);
     free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n);
     free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tbf_scratch);
+    free(dp);
     return 0;
 }
+
+extern "C" int emu_num_keys(void) { return IPX_NUM_KEYS; }
+extern "C" int emu_key(int kclass, int sub) { return IPX_KEY(kclass, sub); }

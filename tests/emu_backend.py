@@ -42,7 +42,16 @@ class EmuAligner:
     def __init__(self, device=0, match_score=2, mismatch_penalty=2, matrix=None):
         self._L = C.CDLL(build_emu())
         self.device = device
+        self.routing = 0
+        self.launches = {}
         self.set_scoring(match_score, mismatch_penalty, matrix)
+
+    def set_routing(self, flags):
+        """speed-only routing switches (IPX_ROUTE_* of ipx_types.h / indelpost_amd.batch.ROUTE_*)"""
+        self.routing = int(flags)
+
+    def key(self, kclass, sub):
+        return int(self._L.emu_key(kclass, sub))
 
     def set_scoring(self, match_score=2, mismatch_penalty=2, matrix=None, flag=1, filters=0, filterd=0, score_size=2):
         self.matrix = dna_score_matrix(match_score, mismatch_penalty) if matrix is None else np.ascontiguousarray(matrix, np.int8)
@@ -54,14 +63,18 @@ class EmuAligner:
         cap = 2 * int(jobs.read_off[-1]) + 64 * n + 64
         pool = np.zeros(cap, np.uint32)
         st = C.c_uint32(0)
+        launches = np.zeros(int(self._L.emu_num_keys()), np.int32)
+        pass_jobs = np.zeros(16, np.uint32)
         reads = np.concatenate([jobs.reads, np.zeros(8, np.int8)])
         refs = np.concatenate([jobs.refs, np.zeros(8, np.int8)])
         with _EMU_LOCK:
             self._L.emu_align_batch(_p(reads), _p(jobs.read_off), _p(refs), _p(jobs.ref_off), _p(jobs.ref_id),
                                     _p(jobs.gap_open), _p(jobs.gap_ext), _p(jobs.mask_len), _p(self.matrix),
                                     C.c_int64(n), C.c_int32(jobs.n_refs), self.flag, self.filters, self.filterd,
-                                    self.score_size, _p(rec), _p(pool), C.c_uint32(cap), C.byref(st))
+                                    self.score_size, self.routing, _p(rec), _p(pool), C.c_uint32(cap), C.byref(st), _p(launches), _p(pass_jobs))
         self.status = st.value
+        self.launches = {int(k): int(launches[k]) for k in np.flatnonzero(launches)}
+        self.pass_jobs = pass_jobs[:8].tolist()     # jobs per pass (IPX_PASS_* order of csrc/ipx_types.h)
         used = int((rec["cigar_off"].astype(np.int64) + rec["cigar_len"]).max()) if n else 0
         return BatchResult(rec, pool[:used])
 
@@ -82,6 +95,9 @@ class EmuAligner:
         pass
 
     def kernel_times(self):
+        return {}
+
+    def kernel_units(self):
         return {}
 
     def last_run_ms(self):

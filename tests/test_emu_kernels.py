@@ -7,6 +7,7 @@ GPU.  The GPU parity tests (test_gpu_parity.py) run the same cases through the r
 import numpy as np
 import pytest
 
+from indelpost_amd import batch as R
 from indelpost_amd.batch import JobTable
 from tests.conftest import codes
 
@@ -153,18 +154,17 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
         assert res.as_dict(i) == port.align(reads[i], w, mat, 3, 1, mask_len=masks[i]), i
 
 
-@pytest.mark.parametrize("knobs", [("IPX_NO_BYTE_SAFE",), ("IPX_NO_PERM_PROFILE", "IPX_TBF_FUSE_MAX"),
-                                   ("IPX_NO_WORD_FIRST", "IPX_NO_BYTE_SAFE", "IPX_NO_PERM_PROFILE")])
-def test_emu_routing_knobs_off(emu, golden_c, monkeypatch, knobs):
-    """The speed-only routing decisions (skip the lower-bound stage for reads that cannot overflow, 16-bit
-    pass first, register-selector profile) must not change any result: golden vectors with each turned off."""
-    for k in knobs:
-        monkeypatch.setenv(k, "0" if k == "IPX_TBF_FUSE_MAX" else "1")     # FUSE_MAX=0: one traceback launch per band width
+@pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE), (R.ROUTE_NO_MC_LDS,),
+                                   (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE)])
+def test_emu_routing_knobs_off(emu, golden_c, knobs):
+    """The speed-only routing decisions (the upper-bound stage, 16-bit pass first, register-selector profile, column
+    maxima in LDS, fused traceback launch) must not change any result: golden vectors with each turned off."""
     groups = {}
     for c in golden_c[160:320]:
         groups.setdefault((c["match"], c["mismatch"]), []).append(c)
     for (ms, mm), cs in groups.items():
         a = emu(0, ms, mm)
+        a.set_routing(sum(knobs))
         jobs = JobTable.from_sequences([codes(c["read"]) for c in cs], [codes(c["ref"]) for c in cs],
                                        np.arange(len(cs), dtype=np.int32), [c["gap_open"] for c in cs],
                                        [c["gap_ext"] for c in cs], encoded=True)
@@ -172,3 +172,83 @@ def test_emu_routing_knobs_off(emu, golden_c, monkeypatch, knobs):
         assert a.status == 0
         for i, c in enumerate(cs):
             assert res.as_dict(i) == c["expect"], "knobs %s scoring %s case %d" % (knobs, (ms, mm), i)
+
+
+# kernel classes of ipx_pipeline.h (timing keys = class * 256 + job class)
+K_BYTE_LOW, K_BYTE_CHECK, K_BYTE_HIGH, K_BYTE_EXACT, K_WORD_FIRST, K_WORD_FWD, K_BYTE_REV, K_WORD_REV = range(2, 10)
+SLOW_BASE = 65
+
+
+def _launched(a, kclass):
+    return sorted(k % 256 for k in a.launches if k // 256 == kclass)
+
+
+def test_emu_bracket_certifies_or_steps(emu, oracle_mod, port):
+    """8-bit-resident reads whose scores run far above 128 (75 bp at match 3): the lower-bound stage cannot settle them,
+    the upper-bound stage certifies most, the stepped pass takes the rest -- and with the bracket switched off the
+    stepped pass takes all of them.  Same records either way, equal to the oracle."""
+    rng = np.random.default_rng(21)
+    w = rng.integers(0, 4, 260).astype(np.int8)
+    lowc = np.resize(np.array([0, 1, 0, 0, 1, 1], np.int8), 200)          # low complexity: many equal-scoring paths
+    reads, refs_id = [], []
+    for i in range(20):
+        st = int(rng.integers(0, 170))
+        r = w[st:st + 75].copy()
+        if i % 3 == 0:
+            r[int(rng.integers(5, 70))] ^= 2
+        if i % 4 == 0:
+            r = np.concatenate([r[:40], r[43:], w[st + 75:st + 78]])      # 3 bp deletion
+        reads.append(r); refs_id.append(0)
+    for i in range(8):
+        st = int(rng.integers(0, 100))
+        r = lowc[st:st + 70 + i].copy()
+        r[int(rng.integers(0, len(r)))] ^= 1
+        reads.append(r); refs_id.append(1)
+    jobs = JobTable.from_sequences(reads, [w, lowc], refs_id, [3, 5, 4, 3] * 7, [1, 0, 1, 0] * 7, encoded=True)
+    mat = oracle_mod.dna_matrix(3, 2)
+    a = emu(0, 3, 2)
+    res = a.align(jobs)
+    assert a.status == 0
+    for i, r in enumerate(reads):
+        assert res.as_dict(i) == port.align(r, [w, lowc][refs_id[i]], mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])), i
+    assert (res.records["mode"] == 0).all()                               # 8-bit semantics throughout
+    assert _launched(a, K_BYTE_LOW) == [5] and _launched(a, K_BYTE_HIGH) == [5] and _launched(a, K_WORD_FIRST) == []
+    n_low, n_high, n_exact = a.pass_jobs[1], a.pass_jobs[3], a.pass_jobs[4]
+    assert n_low == 28 and n_high >= 20 and n_exact < n_high          # most of what reaches the upper-bound stage is certified
+    b = emu(0, 3, 2)
+    b.set_routing(R.ROUTE_NO_BRACKET)
+    res2 = b.align(jobs)
+    assert _launched(b, K_BYTE_HIGH) == [] and b.pass_jobs[3] == 0 and b.pass_jobs[4] == n_high
+    for f in res.records.dtype.names:
+        if f != "cigar_off":
+            assert np.array_equal(res.records[f], res2.records[f]), f
+    assert res.cigar_strings() == res2.cigar_strings()
+
+
+def test_emu_slow_gap_jobs_are_a_class_of_their_own(emu, oracle_mod, port):
+    """gap_open <= gap_ext (e.g. is_perfect_match's gap_open = gap_ext = len(read), varaln.pyx:1230) needs the stepped
+    lazy-F loop: such jobs form their own planner classes, the other jobs of the batch keep the kernels without it."""
+    rng = np.random.default_rng(23)
+    w = rng.integers(0, 4, 300).astype(np.int8)
+    reads, go, ge = [], [], []
+    for i in range(24):
+        L = (60, 150)[i % 2]
+        st = int(rng.integers(0, 300 - L))
+        r = w[st:st + L].copy()
+        r[int(rng.integers(0, L))] ^= 3
+        if i % 5 == 0:
+            r = np.concatenate([r[:20], r[24:]])
+        reads.append(r)
+        g = [(3, 1), (L, L), (5, 0), (1, 2), (2, 2), (4, 1)][i % 6]       # (L, L) narrows to uint8 like the reference's arguments
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), go, ge, encoded=True)
+    mat = oracle_mod.dna_matrix(3, 2)
+    a = emu(0, 3, 2)
+    res = a.align(jobs)
+    assert a.status == 0
+    for i, r in enumerate(reads):
+        assert res.as_dict(i) == port.align(r, w, mat, go[i], ge[i]), i
+    wf = _launched(a, K_WORD_FIRST)
+    assert any(c < SLOW_BASE for c in wf) and any(c >= SLOW_BASE for c in wf)     # 150 bp reads: fast and slow classes side by side
+    low = _launched(a, K_BYTE_LOW)
+    assert any(c < SLOW_BASE for c in low) and any(c >= SLOW_BASE for c in low)   # 60 bp reads likewise
