@@ -152,6 +152,7 @@ IPX_DEV int next_pass_key(const IpxBatch &b, const IpxResult &r, int readLen, bo
     case IPX_MODE_PENDING:
         if (b.score_size == 1) { pass = IPX_PASS_WORD_FWD; lanes = 8; }                      // 16-bit profile only (ssw.c:853-855)
         else if (b.score_size == 2 && b.word_first_len > 0 && readLen >= b.word_first_len) { pass = IPX_PASS_WORD_FIRST; lanes = 8; }
+        else if (readLen < b.byte_safe_len && (!b.use_bracket || readLen < b.bracket_min_len)) pass = IPX_PASS_BYTE_EXACT;
         else pass = IPX_PASS_BYTE_LOW;                                                       // ssw.c:842-843
         break;
     case IPX_MODE_NEED_BYTE_CHECK: pass = IPX_PASS_BYTE_CHECK; break;

@@ -17,6 +17,7 @@
 struct IpxWorkspace {
     IpxPlan plan[IPX_NUM_PASSES];
     uint32_t *plan_tables;              // [IPX_NUM_PASSES][2][IPX_NUM_CLASSES]: count and cursor of every pass, the dynamic passes' part zeroed per run
+    uint32_t *exact_starters;           // [IPX_NUM_CLASSES] jobs that START in the stepped 8-bit pass (host-known): seeds its count row every run
     uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: 7 lists (first band 1..7) of n_jobs slots; 8 counters, the 8th = tb_esc_n
     uint32_t *tb_esc, *tb_esc_n;        // jobs the fast traceback hands to the general (one wave per job) kernel
     IpxTbScratch tb1;
@@ -36,7 +37,7 @@ struct IpxDims {
     // derived by ipx_dims_finish for the current scoring parameters: classes (segLen, + IPX_SLOW_BASE when slow) present
     uint8_t has8_low[IPX_NUM_CLASSES], has8_wf[IPX_NUM_CLASSES];     // 8-bit classes of the reads that start in the 8-bit / in the 16-bit-first pass
     uint8_t has16_low[IPX_NUM_CLASSES], has16_wf[IPX_NUM_CLASSES];   // 16-bit classes of the same two sets
-    uint8_t any_wf, any_low;
+    uint8_t any_wf, any_low;           // some read starts in the 16-bit-first pass / in the 8-bit lower-bound stage
 };
 
 static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
@@ -179,7 +180,13 @@ static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, 0), IPX_FIRST_DYNAMIC_PASS * 2 * IPX_NUM_CLASSES);
     if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, 16, true);
-    if (b.score_size != 1) ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW], IPX_PASS_BYTE_LOW, 8, true);
+    if (b.score_size != 1) {
+        ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW], IPX_PASS_BYTE_LOW, 8, true);
+        // jobs that start in the stepped pass: counted now, their count seeds that pass's (dynamic) row in every run
+        be.zero_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, IPX_NUM_CLASSES);
+        be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, (int)IPX_PASS_BYTE_EXACT);
+        be.copy_u32(ws.exact_starters, ws.plan[IPX_PASS_BYTE_EXACT].count, IPX_NUM_CLASSES);
+    }
 }
 
 template <class BE>
@@ -192,6 +199,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     be.zero_u32(b.cigar_cursor, 1);
     be.zero_u32(ws.tb_list_n, 8);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, IPX_FIRST_DYNAMIC_PASS), (IPX_NUM_PASSES - IPX_FIRST_DYNAMIC_PASS) * 2 * IPX_NUM_CLASSES);
+    if (b.score_size != 1) be.copy_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, ws.exact_starters, IPX_NUM_CLASSES);
 
     const bool wf = b.score_size == 2 && d.any_wf;
     if (wf) {
@@ -277,6 +285,20 @@ static inline int ipx_word_first_len(const int8_t *mat, int bias)
     return (cap * 14 / 10 + mx - 1) / mx;
 }
 
+// shortest read that could overflow the 8-bit pass: len * max(mat) >= 255 - bias
+static inline int ipx_byte_safe_len(const int8_t *mat, int bias)
+{
+    int mx = 0;
+    for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
+    if (mx <= 0) return 0x7FFFFFFF;
+    return (255 - bias + mx - 1) / mx;
+}
+// reads shorter than this start in the stepped 8-bit pass (next_pass_key, IPX_MODE_PENDING)
+static inline int ipx_exact_start_len(int byte_safe_len, int bracket_min_len, bool use_bracket)
+{
+    return use_bracket ? (byte_safe_len < bracket_min_len ? byte_safe_len : bracket_min_len) : byte_safe_len;
+}
+
 // The bracket (lower + upper bound stage) costs two closed-form passes; the stepped pass costs one plus the stepping,
 // which grows with the number of columns whose carries sit in signed-compare territory (>= 128).  A read that can only
 // just get there (best possible score below ~1.25 x 128) has few such columns and is cheaper stepped (r02: config 2a,
@@ -291,7 +313,7 @@ static inline int ipx_bracket_min_len(const int8_t *mat)
 }
 
 // which classes can occur in which pass, for the current scoring parameters (host-known facts only)
-static inline void ipx_dims_finish(IpxDims &d, int word_first_len, int score_size)
+static inline void ipx_dims_finish(IpxDims &d, int word_first_len, int score_size, int exact_start_len)
 {
     memset(d.has8_low, 0, sizeof d.has8_low); memset(d.has8_wf, 0, sizeof d.has8_wf);
     memset(d.has16_low, 0, sizeof d.has16_low); memset(d.has16_wf, 0, sizeof d.has16_wf);
@@ -305,7 +327,7 @@ static inline void ipx_dims_finish(IpxDims &d, int word_first_len, int score_siz
             const bool wfirst = score_size == 2 && word_first_len > 0 && len >= word_first_len;
             (wfirst ? d.has8_wf : d.has8_low)[c8 + slow * IPX_SLOW_BASE] = 1;
             (wfirst ? d.has16_wf : d.has16_low)[c16 + slow * IPX_SLOW_BASE] = 1;
-            if (wfirst) d.any_wf = 1; else d.any_low = 1;
+            if (wfirst) d.any_wf = 1; else if (len >= exact_start_len) d.any_low = 1;   // (shorter ones start in the stepped pass)
         }
 }
 

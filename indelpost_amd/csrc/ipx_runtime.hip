@@ -105,13 +105,13 @@ struct HipBackend {
     // find; many find none.  A block that finds nothing still has to be dispatched, and on a GPU busy with other
     // streams' kernels it waits for register space first.  So launches are sized from the tile counts the planner
     // saw in the PREVIOUS run of this context (read back in ipx_sync).  Any grid is correct (blocks stride over the
-    // tiles); a wrong guess only costs speed, and never less than 1/16 of the full grid is launched.
+    // tiles); a wrong guess only costs speed.  (r02: a floor of 1/16 of the full grid made every launch that finds
+    // nothing -- most classes of most passes -- queue a thousand blocks behind the other streams' kernels.)
     int sized(int64_t tiles) const
     {
         const int64_t full = dp_grid();
         if (!c->prev_valid) return (int)full;
-        int64_t g = tiles + tiles / 4 + 8, lo = full / 16 > 0 ? full / 16 : 1;
-        if (g < lo) g = lo;
+        const int64_t g = tiles + tiles / 4 + 8;
         return (int)(g < full ? g : full);
     }
     int dp_grid(int pass, int cls) const { return sized(c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + cls]); }
@@ -142,6 +142,11 @@ struct HipBackend {
         return (int)(g < cap ? g : cap);
     }
     void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 256 + cls) * 32 + na; }
+    void copy_u32(uint32_t *dst, const uint32_t *src, int n)
+    {
+        hipError_t e = hipMemcpyAsync(dst, src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    }
     void zero_u32(uint32_t *p, int n)
     {
         hipError_t e = hipMemsetAsync(p, 0, sizeof(uint32_t) * (size_t)n, c->stream);
@@ -303,7 +308,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
         c->perm.ensure(12 * (size_t)n_jobs + 16) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
         c->tb_esc.ensure(4 * (size_t)n_jobs + 4) ||
-        c->small.ensure(4 * ((size_t)IPX_PLAN_TABLE_WORDS + (size_t)IPX_NUM_PASSES * 3 * (IPX_NUM_CLASSES + 1) + 64)))
+        c->small.ensure(4 * ((size_t)IPX_PLAN_TABLE_WORDS + (size_t)IPX_NUM_PASSES * 3 * (IPX_NUM_CLASSES + 1) + IPX_NUM_CLASSES + 64)))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
     if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
@@ -372,6 +377,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.plan_tables = sm; sm += IPX_PLAN_TABLE_WORDS;
     uint32_t *offs = sm; sm += (size_t)IPX_NUM_PASSES * 2 * (IPX_NUM_CLASSES + 1);
     c->stats_dev = sm; sm += (size_t)IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1);
+    c->ws.exact_starters = sm; sm += IPX_NUM_CLASSES;
     for (int ps = 0; ps < IPX_NUM_PASSES; ++ps) {
         IpxPlan &p = c->ws.plan[ps];
         p.count = ipx_plan_count_of(c->ws.plan_tables, ps);
@@ -415,6 +421,7 @@ int ipx_run(ipx_ctx *c)
     b.word_first_len = (c->routing & IPX_ROUTE_NO_WORD_FIRST) ? 0 : ipx_word_first_len(c->mat, c->bias);
     b.use_bracket = ipx_perm_profile_ok(c->mat, c->routing) && !(c->routing & IPX_ROUTE_NO_BRACKET);
     b.bracket_min_len = ipx_bracket_min_len(c->mat);
+    b.byte_safe_len = ipx_byte_safe_len(c->mat, c->bias);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
@@ -422,7 +429,7 @@ int ipx_run(ipx_ctx *c)
     be.zero_u32(b.status, 1);
     if (!c->static_valid && c->n_jobs > 0) {
         // first run of this batch under these parameters: the job lists of the passes every job starts in
-        ipx_dims_finish(c->dims, b.word_first_len, c->score_size);
+        ipx_dims_finish(c->dims, b.word_first_len, c->score_size, ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
         const bool prof = c->profiling;
         c->profiling = false;
         ipx_build_static_plans(be, b, c->ws);

@@ -43,7 +43,8 @@ enum {
     IPX_PASS_BYTE_LOW = 1,        // static: 8-bit forward pass, lower-bound stage, every other read
     IPX_PASS_BYTE_CHECK = 2,      // 8-bit lower-bound stage for word-first reads whose overflow could not be proven
     IPX_PASS_BYTE_HIGH = 3,       // 8-bit forward pass, upper-bound stage: certifies the lower-bound outputs
-    IPX_PASS_BYTE_EXACT = 4,      // 8-bit forward pass with the reference's stepped lazy-F, for what the bracket left open
+    IPX_PASS_BYTE_EXACT = 4,      // 8-bit forward pass with the reference's stepped lazy-F: what the bracket left open, and (a static
+                                  //   part, counted once per batch) short reads that can neither overflow nor profit from the bracket
     IPX_PASS_WORD_FWD = 5,        // 16-bit forward pass after an 8-bit overflow (ssw.c:844-847)
     IPX_PASS_BYTE_REV = 6,
     IPX_PASS_WORD_REV = 7,
@@ -88,6 +89,9 @@ struct IpxBatch {
     int32_t word_first_len;     // reads at least this long take the 16-bit pass first (0 = never); speed only
     int32_t bracket_min_len;    // reads at least this long take the lower/upper-bound bracket when the lower-bound stage cannot
                                 //   settle them, shorter ones (few columns with big carries) the stepped pass directly; speed only
+    int32_t byte_safe_len;      // reads shorter than this cannot reach 255-bias (len * max(mat) < 255-bias): the lower-bound stage
+                                //   has nothing to offer them but the bracket; below bracket_min_len they start in the stepped
+                                //   pass directly; speed only
     uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)

@@ -169,6 +169,7 @@ struct EmuBackend {
     int flat_grid(int64_t n) const { return n > 512 ? 2 : 1; }
     int plan_grid(int64_t n) const { return n > 100 ? 3 : 1; }
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
+    void copy_u32(uint32_t *dst, const uint32_t *src, int n) { memcpy(dst, src, sizeof(uint32_t) * (size_t)n); }
     void note_dp(int, int, int, int) {}
     template <class K, class... A>
     void launch(int kclass, K kern, int grid, int block, int lds, A... args)
@@ -221,15 +222,17 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.bias = -bias;
     b.word_first_len = (routing & IPX_ROUTE_NO_WORD_FIRST) ? 0 : ipx_word_first_len(mat, -bias);
     b.use_bracket = ipx_perm_profile_ok(mat, routing) && !(routing & IPX_ROUTE_NO_BRACKET);
-    b.bracket_min_len = getenv("IPX_EMU_BRACKET_ALWAYS") ? 0 : ipx_bracket_min_len(mat);
+    b.bracket_min_len = ipx_bracket_min_len(mat);
+    b.byte_safe_len = ipx_byte_safe_len(mat, -bias);
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
-    ipx_dims_finish(d, b.word_first_len, score_size);
+    ipx_dims_finish(d, b.word_first_len, score_size, ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
 
     b.maxcol_scratch = zalloc<uint32_t>((size_t)be.dp_grid() * 16 * (size_t)(d.max_ref_len + 8));
     IpxWorkspace ws;
     memset(&ws, 0, sizeof ws);
     ws.plan_tables = zalloc<uint32_t>(IPX_PLAN_TABLE_WORDS);
+    ws.exact_starters = zalloc<uint32_t>(IPX_NUM_CLASSES);
     b.plan_counts = nullptr;
     uint32_t *offs = zalloc<uint32_t>((size_t)IPX_NUM_PASSES * 2 * (IPX_NUM_CLASSES + 1));
     uint32_t *perms = zalloc<uint32_t>(3 * (size_t)n_jobs);      // two static passes + one shared by the dynamic ones
@@ -274,7 +277,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
         }
     free(packed);
     free(b.maxcol_scratch);
-    free(ws.plan_tables); free(offs); free(perms);
+    free(ws.plan_tables); free(ws.exact_starters); free(offs); free(perms);
     free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n);
     free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tbf_scratch);
     free(dp);
