@@ -5,7 +5,11 @@ reference exports from ``indelpost/__init__.py`` that lie outside that path (``V
 ``VariantAlignment``, ...) are present as shells that say so when used.
 """
 from .sswpy import SSW, Alignment, force_align, format_force_align          # noqa: F401
-from .localn import make_aligner, align, align_pileup, realign_pileup_jobs  # noqa: F401
+from .localn import (make_aligner, align, align_pileup, realign_pileup_jobs, classify_realigned, find_targets_by_ssw,  # noqa: F401
+                     is_covering_target, is_compatible_repeats)
+from .cigar import findall_indels, make_insertion_first, merge_consecutive_gaps, to_minimal_repeat_unit  # noqa: F401
+from .retarget import (generate_grid, retarget_jobs, grid_align, indel_candidates, get_local_reference,  # noqa: F401
+                       UnsplicedLocalReference, overhang_jobs, overhang_alignment_verdicts, perfect_match_batch)
 from .batch import (GpuAligner, MultiStreamAligner, JobTable, BatchResult, IpxError, align_sharded, device_count,  # noqa: F401
                     dna_score_matrix, encode_dna, cigar_to_string)
 

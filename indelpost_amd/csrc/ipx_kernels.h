@@ -367,13 +367,33 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
     if (PERM && lane < 20) ((int8_t *)lds)[lane] = b.mat[(lane >> 2) * 5 + (lane & 3)];
     IPX_SYNC();
 
-    const uint32_t tile_begin = p.tile_off[cls_lo], tile_end = p.tile_off[cls_hi + 1];
-    for (uint32_t tile = tile_begin + (uint32_t)IPX_BID; tile < tile_end; tile += (uint32_t)IPX_GDIM) {
+    // Block b takes the b-th, (b + gridDim)-th, ... tile of the classes this launch OWNS.  An exact-segLen launch owns its one
+    // class; the sweep launch owns what the exact launches left over (skip_fast / skip_slow) and walks the classes once,
+    // counting only its own tiles -- a sweep grid is sized for those few tiles, so striding over ALL tiles of the pass and
+    // skipping the foreign ones (as an earlier version did) cost each block thousands of class look-ups.
+    int own_cls = cls_lo;                                             // (sweep) class reached by the walk
+    uint32_t own_base = 0;                                            // (sweep) owned tiles in the classes before own_cls
+    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
         // ---- locate the tile: class (= segLen), first slot in perm, number of reads -------------
-        int cls = cls_lo;
-        while (tile >= p.tile_off[cls + 1]) ++cls;
+        int cls;
+        uint32_t tile;
+        if (EXACT) {
+            cls = cls_lo;
+            tile = p.tile_off[cls] + want;
+            if (tile >= p.tile_off[cls + 1]) break;
+        } else {
+            for (; own_cls <= cls_hi; ++own_cls) {
+                const int sg = own_cls >= IPX_SLOW_BASE ? own_cls - IPX_SLOW_BASE : own_cls;
+                const bool foreign = sg < 64 && (((own_cls >= IPX_SLOW_BASE ? skip_slow : skip_fast) >> sg) & 1ull);   // owned by an exact-segLen launch
+                const uint32_t n = foreign ? 0u : p.tile_off[own_cls + 1] - p.tile_off[own_cls];
+                if (want < own_base + n) break;
+                own_base += n;
+            }
+            if (own_cls > cls_hi) break;
+            cls = own_cls;
+            tile = p.tile_off[cls] + (want - own_base);
+        }
         const int seg = cls >= IPX_SLOW_BASE ? cls - IPX_SLOW_BASE : cls;      // class = segLen (+ IPX_SLOW_BASE: gap_open <= gap_ext)
-        if (!EXACT && seg < 64 && (((cls >= IPX_SLOW_BASE ? skip_slow : skip_fast) >> seg) & 1ull)) continue;   // class owned by an exact-segLen launch
         if (!EXACT && seg > SMAX) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL); continue; }   // sweep kernel sized too small (host error)
         const int S = EXACT ? SMAX : (int)xl_first((uint32_t)seg);
         const uint32_t first = p.cls_off[cls] + (tile - p.tile_off[cls]) * NA;

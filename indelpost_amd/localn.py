@@ -6,12 +6,19 @@ Mirrors (all citations into /root/reference/indelpost/localn.pyx):
                                          is_target_by_ssw :223-259 -- two alignments per read
                                          (reference contig with (go, ge); mutant contig with
                                          gap_open=len(read)), collapsed into one GPU batch.
-The string post-processing of is_target_by_ssw (is_covering_target etc., :268-459) consumes only
-the returned Alignment tuples and is not part of this path.
+  is_covering_target, is_compatible_repeats, classify_realigned / find_targets_by_ssw
+                                         the classification that follows the two alignments
+                                         (is_target_by_ssw :257-291, is_covering_target :293-430,
+                                         is_compatible_repeats :433-459): score compare over whole result
+                                         columns, string checks only for the reads that pass it.
+What stays with the caller is everything that needs the BAM read (the filters of :244-249: already
+target, reference-identical, mapq, is_worth_realn): they do not depend on the alignments and arrive
+here as a mask.
 """
 import numpy as np
 
 from .batch import JobTable, encode_dna
+from .cigar import cigar_ptrn, to_minimal_repeat_unit
 from .sswpy import SSW, _alignment_from, _gpu, alignments_from
 
 
@@ -64,3 +71,102 @@ def align_pileup(read_seqs, mut_ref, ref_ref, match_score, mismatch_penalty, gap
     res = g.align(jobs)
     alns = alignments_from(res)
     return list(zip(alns[0::2], alns[1::2]))
+
+
+def is_compatible_repeats(seq, repeat_unit, expected_n_repeats, is_left):
+    """localn.pyx:433-459: walk whole repeat units off the indel-facing end of a flank (the left flank is read
+    right to left).  Incompatible when the flank is nothing but repeats, or holds some but not the expected number."""
+    if is_left:
+        seq, repeat_unit = seq[::-1], repeat_unit[::-1]
+    n, cnt = len(repeat_unit), 0
+    while seq and seq[:n] == repeat_unit:
+        seq = seq[n:]
+        cnt += 1
+    if not seq:
+        return False
+    return not (cnt and cnt != expected_n_repeats)
+
+
+def is_covering_target(readname, read_seq, indel_seq, mut_ref_lt, mut_ref_mid, mut_ref_rt, mut_aln_cigar, read_seq_len,
+                       ref_aln_start, ref_aln_end, read_aln_start, read_aln_end, n_repeats):
+    """localn.pyx:293-430.  Does the read's UNGAPPED alignment to the mutant contig (lt + mid + rt; mid = inserted
+    sequence, empty for a deletion) really span the indel?  1 yes, 0 no, -1 undetermined (flank repeats disagree)."""
+    toks = cigar_ptrn.findall(mut_aln_cigar)
+    if len(toks) > 1:
+        return 0
+    unit = to_minimal_repeat_unit(indel_seq)
+    lt_len, mid_len = len(mut_ref_lt), len(mut_ref_mid)
+    consumed = read_aln_end - read_aln_start + 1
+    from_read_start, to_read_end = read_aln_start == 0, read_aln_end == read_seq_len - 1
+    if ref_aln_end < lt_len or lt_len + mid_len <= ref_aln_start:       # the alignment misses the indel altogether
+        return 0
+    if mid_len:                                                        # insertion
+        if ref_aln_start < lt_len:
+            lt_use = lt_len - ref_aln_start
+            if consumed > lt_use + mid_len:                            # through the insertion and out the other side
+                a = read_aln_start + lt_use
+                lt_ok = is_compatible_repeats(read_seq[read_aln_start:a], unit, n_repeats, is_left=True)
+                rt_ok = is_compatible_repeats(read_seq[a + mid_len:read_aln_end + 1], unit, n_repeats, is_left=False)
+                return 1 if (lt_ok and rt_ok) else -1
+            if to_read_end:
+                return 1
+            rt_use = consumed - lt_use                                  # entered from the left, stopped inside the insertion
+            return 1 if mut_ref_mid[:rt_use] == read_seq[-rt_use:] else 0
+        if from_read_start:                                             # no left flank aligned at all
+            return 1
+        lt_use = lt_len + mid_len - ref_aln_start                       # entered from the right, stopped inside the insertion
+        return 1 if mut_ref_mid[-lt_use:] == read_seq[:lt_use] else 0
+    lt_use = lt_len - ref_aln_start                                     # deletion
+    rt_use = consumed - lt_use
+    a = read_aln_start + lt_use
+    if not (is_compatible_repeats(read_seq[read_aln_start:a], unit, n_repeats, is_left=True)
+            and is_compatible_repeats(read_seq[a:read_aln_end], unit, n_repeats, is_left=False)):
+        return -1
+    if lt_use <= rt_use:
+        return 1 if (from_read_start or lt_use > 2) else 0
+    return 1 if (to_read_end or rt_use > 2) else 0
+
+
+def classify_realigned(read_seqs, pairs, indel_seq, mut_ref_lt, mut_ref_mid, mut_ref_rt, n_repeats, read_names=None):
+    """The verdict of is_target_by_ssw (localn.pyx:257-291) for every realigned read at once.
+
+    pairs[k] = (ref_aln, mut_aln) as align_pileup returns them.  Returns (is_target, undetermined): two bool arrays.
+    The score compare runs over the whole columns; only the reads whose mutant-contig score beats the reference-contig
+    score go through the string checks of is_covering_target."""
+    n = len(pairs)
+    is_target, undetermined = np.zeros(n, bool), np.zeros(n, bool)
+    if n == 0:
+        return is_target, undetermined
+    ref_score = np.fromiter((p[0].optimal_score for p in pairs), np.int64, n)
+    mut_score = np.fromiter((p[1].optimal_score for p in pairs), np.int64, n)
+    for k in np.flatnonzero(mut_score > ref_score):                    # localn.pyx:257
+        m = pairs[k][1]
+        seq = read_seqs[k]
+        v = is_covering_target(read_names[k] if read_names else "", seq, indel_seq, mut_ref_lt, mut_ref_mid, mut_ref_rt, m.CIGAR,
+                               len(seq), m.reference_start, m.reference_end, m.read_start, m.read_end, n_repeats)
+        if v == 1:
+            is_target[k] = True
+        elif v == -1:
+            undetermined[k] = True
+    return is_target, undetermined
+
+
+def find_targets_by_ssw(read_seqs, realign_mask, indel_seq, n_repeats, mut_ref_lt, mut_ref_mid, mut_ref_rt, ref_ref,
+                        match_score, mismatch_penalty, gap_open_penalty, gap_extension_penalty, device=0):
+    """find_by_smith_waterman_realn (localn.pyx:15-68) end to end for one locus: the reads selected by `realign_mask`
+    (the alignment-independent filters of localn.pyx:244-249, decided by the caller) are aligned to the reference and
+    the mutant contig in ONE GPU batch and classified.  Returns (is_target, undetermined, pairs): bool arrays over ALL
+    reads (False where the mask is False) and the Alignment pairs (None where not aligned)."""
+    n = len(read_seqs)
+    mask = np.asarray(realign_mask, bool)
+    idx = np.flatnonzero(mask)
+    sel = [read_seqs[i] for i in idx]
+    pairs = align_pileup(sel, mut_ref_lt + mut_ref_mid + mut_ref_rt, ref_ref, match_score, mismatch_penalty,
+                         gap_open_penalty, gap_extension_penalty, device)
+    t, u = classify_realigned(sel, pairs, indel_seq, mut_ref_lt, mut_ref_mid, mut_ref_rt, n_repeats)
+    is_target, undetermined = np.zeros(n, bool), np.zeros(n, bool)
+    is_target[idx], undetermined[idx] = t, u
+    out = [None] * n
+    for i, p in zip(idx, pairs):
+        out[i] = p
+    return is_target, undetermined, out

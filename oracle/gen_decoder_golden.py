@@ -1,0 +1,184 @@
+"""Golden vectors for the host-side decoders and the target classification (TEST INFRASTRUCTURE, build container only).
+
+The reference modules that hold these functions (utilities.pyx, localn.pyx, varaln.pyx) `cimport pysam` at module
+level and cannot be compiled or imported here (no pysam).  The functions themselves are plain Python
+over strings: this script reads their TEXT from /root/reference at generation time, takes the bodies of the named
+functions as they stand (for the one `cdef int` function the Cython type words are dropped mechanically -- the
+statements are untouched), executes them in a scratch namespace and records INPUTS and OUTPUTS as data in
+tests/golden/decoder_cases.json.  No reference text is written anywhere; tests/test_decoders.py replays the inputs
+through indelpost_amd's own implementations.
+
+    python oracle/gen_decoder_golden.py
+"""
+import collections
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O                                   # noqa: E402
+
+REF = "/root/reference/indelpost"
+Alignment = collections.namedtuple("Alignment", "CIGAR optimal_score sub_optimal_score reference_start reference_end read_start read_end")
+LET = "ACGT"
+
+
+def function_text(path, name):
+    """the source block of top-level function `name` (def / cpdef / cdef), dedented as it stands"""
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^(def|cpdef \w+|cdef \w+) %s\s*\(" % re.escape(name), l))
+    end = start + 1
+    while end < len(lines) and (lines[end].strip() == "" or lines[end][0] in " \t)"):
+        end += 1
+    return "\n".join(lines[start:end])
+
+
+def strip_cython_types(src):
+    """`cdef int f(str a, int b):` -> `def f(a, b):`; `cdef T x = e` -> `x = e`; bare `cdef T x` declarations dropped"""
+    types = r"(?:str|int|bint|list|tuple|dict|object)"
+    out = []
+    for line in src.split("\n"):
+        line = re.sub(r"^(?:cdef|cpdef) %s (\w+)\(" % types, r"def \1(", line)
+        line = re.sub(r"^(\s+)%s (\w+,?)\s*$" % types, r"\1\2", line)                     # one typed parameter per line
+        m = re.match(r"^(\s+)cdef %s (\w+)( = .*)?$" % types, line)
+        if m:
+            line = (m.group(1) + m.group(2) + m.group(3)) if m.group(3) else ""
+        out.append(line)
+    return "\n".join(out)
+
+
+def load_reference_functions():
+    ns = {"re": re, "cigar_ptrn": re.compile(r"[0-9]+[MIDNSHPX=]")}
+    for fname, names in (("utilities.pyx", ["most_common", "to_minimal_repeat_unit", "merge_consecutive_gaps", "make_insertion_first"]),
+                         ("localn.pyx", ["findall_indels", "is_compatible_repeats", "is_covering_target"]),
+                         ("varaln.pyx", ["generate_grid"])):
+        for n in names:
+            exec(compile(strip_cython_types(function_text(os.path.join(REF, fname), n)), "<%s:%s>" % (fname, n), "exec"), ns)
+    return ns
+
+
+def s(codes):
+    return "".join(LET[int(c)] for c in codes)
+
+
+def mutate(rng, seq, sub=0.02, indel=0.01):
+    out = []
+    i = 0
+    while i < len(seq):
+        u = rng.random()
+        if u < sub:
+            out.append(LET[int(rng.integers(0, 4))]); i += 1
+        elif u < sub + indel / 2:
+            i += int(rng.integers(1, 4))
+        elif u < sub + indel:
+            out.extend(LET[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 4))))
+        else:
+            out.append(seq[i]); i += 1
+    return "".join(out)
+
+
+def port_alignment(port, read, ref, mat, go, ge):
+    e = port.align(O.encode(read), O.encode(ref), mat, go, ge)
+    return Alignment(O.cigar_string(e["cigar"]), e["score1"], e["score2"], e["ref_begin1"], e["ref_end1"], e["read_begin1"], e["read_end1"])
+
+
+def main():
+    O.build()
+    F = load_reference_functions()
+    port = O.Backend("port")
+    mat = O.dna_matrix(3, 2)
+    rng = np.random.default_rng(20260217)
+    out = {"generator": "oracle/gen_decoder_golden.py", "cigar": [], "repeat_unit": [], "findall_indels": [], "compatible_repeats": [],
+           "covering_target": [], "grid": []}
+
+    for _ in range(300):                                          # CIGAR token shuffling
+        toks = [str(int(rng.integers(1, 30))) + "MMMIDID"[int(rng.integers(0, 7))] for _ in range(int(rng.integers(1, 10)))]
+        cs = "".join(toks)
+        out["cigar"].append({"cigar": cs, "merged": F["merge_consecutive_gaps"](list(toks)), "insertion_first": F["make_insertion_first"](cs)})
+    for _ in range(120):
+        unit = s(rng.integers(0, 4, int(rng.integers(1, 5))))
+        seq = unit * int(rng.integers(1, 5)) + (s(rng.integers(0, 4, int(rng.integers(0, 3)))) if rng.random() < 0.4 else "")
+        out["repeat_unit"].append({"seq": seq, "unit": F["to_minimal_repeat_unit"](seq)})
+
+    genome = s(rng.integers(0, 4, 4000))
+    for k in range(160):                                          # findall_indels on real alignments (port = pinned restatement of ssw.c)
+        st = int(rng.integers(100, 3500))
+        ref = genome[st:st + int(rng.integers(120, 320))]
+        a = int(rng.integers(0, max(1, len(ref) - 100)))
+        read = mutate(rng, ref[a:a + int(rng.integers(60, 150))], sub=0.03, indel=float(rng.choice([0.0, 0.02, 0.05])))
+        if not read:
+            continue
+        go, ge = [(3, 1), (3, 0), (5, 1), (4, 0), (1, 0), (0, 0)][k % 6]
+        aln = port_alignment(port, read, ref, mat, go, ge)
+        if not aln.CIGAR:
+            continue
+        quals = [int(q) for q in rng.integers(2, 41, len(read))] if k % 3 == 0 else None
+        snv = k % 2 == 0
+        res = F["findall_indels"](aln, st + 1 + aln.reference_start, ref, read, report_snvs=snv, basequals=quals)
+        out["findall_indels"].append({"aln": list(aln), "genome_aln_pos": st + 1 + aln.reference_start, "ref_seq": ref, "read_seq": read,
+                                      "report_snvs": snv, "basequals": quals, "expect": res})
+
+    for _ in range(150):
+        unit = s(rng.integers(0, 4, int(rng.integers(1, 4))))
+        seq = unit * int(rng.integers(0, 4)) + s(rng.integers(0, 4, int(rng.integers(0, 6))))
+        if rng.random() < 0.5:
+            seq = seq[::-1]
+        n, left = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+        out["compatible_repeats"].append({"seq": seq, "unit": unit, "n": n, "is_left": left, "expect": bool(F["is_compatible_repeats"](seq, unit, n, left))})
+
+    for k in range(400):                                          # is_covering_target on ungapped alignments to mutant contigs
+        pos = int(rng.integers(400, 3500))
+        is_ins = k % 2 == 0
+        size = int(rng.choice([1, 2, 3, 6, 12]))
+        if k % 5 == 0:                                            # indel inside a short tandem repeat
+            unit = s(rng.integers(0, 4, int(rng.integers(1, 3))))
+            rep = unit * int(rng.integers(2, 6))
+            g = genome[:pos] + rep + genome[pos + len(rep):]
+            indel_seq = unit * max(1, size // len(unit))
+        else:
+            g = genome
+            indel_seq = s(rng.integers(0, 4, size)) if is_ins else g[pos:pos + size]
+        lt = g[pos - int(rng.integers(60, 140)):pos]
+        if is_ins:
+            mid, rt = indel_seq, g[pos:pos + int(rng.integers(60, 140))]
+        else:
+            mid, rt = "", g[pos + len(indel_seq):pos + len(indel_seq) + int(rng.integers(60, 140))]
+        contig = lt + mid + rt
+        a = int(rng.integers(0, max(1, len(contig) - 40)))
+        read = mutate(rng, contig[a:a + int(rng.integers(30, 120))], sub=float(rng.choice([0.0, 0.02])), indel=0.0)
+        if k % 7 == 0:
+            read = s(rng.integers(0, 4, int(rng.integers(0, 12)))) + read       # soft-clip-like junk at the start
+        if len(read) < 8:
+            continue
+        aln = port_alignment(port, read, contig, mat, len(read), 1)               # forced ungapped (localn.pyx:255)
+        if not aln.CIGAR:
+            continue
+        n_rep = int(rng.integers(0, 5))
+        args = ["r%d" % k, read, indel_seq, lt, mid, rt, aln.CIGAR, len(read), aln.reference_start, aln.reference_end, aln.read_start,
+                aln.read_end, n_rep]
+        out["covering_target"].append({"args": args, "expect": int(F["is_covering_target"](*args))})
+    for cig in ("20M2I30M", "10M1D40M"):                          # a gapped CIGAR is never a covering alignment (localn.pyx:311-312)
+        args = ["g", genome[:52], "AC", genome[100:130], "AC", genome[130:160], cig, 52, 0, 51, 0, 51, 0]
+        out["covering_target"].append({"args": args, "expect": int(F["is_covering_target"](*args))})
+
+    class T:                                                      # generate_grid only reads len(target.indel_seq)
+        def __init__(self, n):
+            self.indel_seq = "A" * n
+    for auto in (True, False):
+        for go, ge in ((3, 1), (4, 0), (6, 2), (3, 0)):
+            for n in (1, 19, 20, 45):
+                out["grid"].append({"auto": auto, "gap_open": go, "gap_ext": ge, "indel_len": n,
+                                    "expect": [list(x) for x in F["generate_grid"](auto, go, ge, T(n))]})
+
+    with open(os.path.join(ROOT, "tests", "golden", "decoder_cases.json"), "w") as f:
+        json.dump(out, f)
+        f.write("\n")
+    print({k: len(v) for k, v in out.items() if isinstance(v, list)})
+
+
+if __name__ == "__main__":
+    main()
