@@ -14,7 +14,8 @@
  *      malloc'd by the callee and freed by align_destroy; the profile BORROWS read and mat,
  *      ssw.c:803-804), same NULL-on-error convention (ssw.c:848-859).  Each call runs one
  *      alignment on GPU 0 -- correct but latency-bound; it exists so the reference's binding links
- *      unchanged.  The inline cigar helpers of ssw.h:171-190 are provided below under the same names.
+ *      unchanged.  The inline cigar helpers of ssw.h:171-192 (to_cigar_int, cigar_int_to_op, cigar_int_to_len) and the
+ *      encoded_ops table they use (ssw.h:34) are provided below under the same names.
  *
  *  (2) The batched entry points that the reference's per-read loop
  *      (localn.pyx:47-66, 464-472 -> sswpy.pyx:149-178, 199-225) collapses into: a whole job table
@@ -60,13 +61,26 @@ s_align *ssw_align(const s_profile *prof, const int8_t *ref, int32_t refLen, con
 void align_destroy(s_align *a);
 
 #define IPX_MAPSTR "MIDNSHP=X"
+#ifndef MAPSTR
+#define MAPSTR IPX_MAPSTR                                   /* ssw.h:29 */
+#endif
+#ifndef BAM_CIGAR_SHIFT
+#define BAM_CIGAR_SHIFT 4u                                  /* ssw.h:30-32 */
+#endif
+/* ASCII CIGAR letter -> BAM opcode 0..8, everything else 0 (ssw.h:34, table ssw.c:127): defined by the library */
+extern const uint8_t encoded_ops[];
+
+static inline uint32_t to_cigar_int(uint32_t length, char op_letter)   /* ssw.h:171-173 */
+{
+    return (length << BAM_CIGAR_SHIFT) | (encoded_ops[(int)op_letter]);
+}
 static inline char cigar_int_to_op(uint32_t cigar_int)      /* ssw.h:182-184 */
 {
     return (cigar_int & 0xfU) > 8 ? 'M' : IPX_MAPSTR[cigar_int & 0xfU];
 }
 static inline uint32_t cigar_int_to_len(uint32_t cigar_int) /* ssw.h:190-192 */
 {
-    return cigar_int >> 4;
+    return cigar_int >> BAM_CIGAR_SHIFT;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -126,6 +140,17 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
 int ipx_run(ipx_ctx *c);                      /* enqueue the whole pipeline on the context's stream */
 int ipx_sync(ipx_ctx *c);                     /* wait; returns IPX_OK or the first error of the run */
 int ipx_download(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops);
+
+/* Transfers that do not wait.  ipx_set_async_io(c, 1): the caller promises to keep the buffers it passes to ipx_upload
+ * valid and unchanged until the next ipx_sync, so ipx_upload only enqueues its copies (truly asynchronous when the buffers
+ * are page-locked: ipx_pin_host / ipx_unpin_host wrap hipHostRegister for caller-owned memory).  ipx_download_async, after
+ * ipx_sync, enqueues the copies of the records and of the n_cigar_ops CIGAR ops of the last run into caller buffers that
+ * must stay valid until ipx_wait returns. */
+int ipx_set_async_io(ipx_ctx *c, int on);
+int ipx_pin_host(void *p, int64_t bytes);
+int ipx_unpin_host(void *p);
+int ipx_download_async(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops);
+int ipx_wait(ipx_ctx *c);
 
 /* upload + run + sync + download in one call */
 int ipx_align_batch(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const int8_t *refs,

@@ -16,19 +16,52 @@ from .batch import (GpuAligner, MultiStreamAligner, JobTable, BatchResult, IpxEr
 __version__ = "0.1.0"
 
 
-def _out_of_scope(name, where):
-    class _Shell:
-        __doc__ = ("%s (%s) is outside the hot path this package replaces; use the reference "
-                   "implementation for it and plug this package in at make_aligner()/align()." % (name, where))
-
-        def __init__(self, *a, **k):
-            raise NotImplementedError(self.__doc__)
-    _Shell.__name__ = name
-    return _Shell
+_WHY = ("%s (%s) is outside the hot path this package replaces (SURVEY.md section 8: pysam I/O, pileup and contig "
+        "construction, variant normalisation); use the reference implementation for it and plug this package in at "
+        "make_aligner()/align() or, better, at the batched drivers align_pileup / find_targets_by_ssw / grid_align.")
 
 
-Variant = _out_of_scope("Variant", "indelpost/variant.pyx:62")
-NullVariant = _out_of_scope("NullVariant", "indelpost/variant.pyx:9")
-VariantAlignment = _out_of_scope("VariantAlignment", "indelpost/varaln.pyx:41")
-Contig = _out_of_scope("Contig", "indelpost/contig.pyx:19")
-FailedContig = _out_of_scope("FailedContig", "indelpost/contig.pyx:338")
+class NullVariant:
+    """indelpost/variant.pyx:9-60: what VariantAlignment returns when the target is not found; falsy, ref == alt == the
+    reference base at the locus.  Small enough to be kept whole (reference: a pysam.FastaFile duck type with fetch())."""
+
+    def __init__(self, chrom, pos, reference):
+        self.chrom = chrom
+        self.pos = pos
+        self.ref = reference.fetch(chrom, pos - 1, pos)
+        self.alt = self.ref
+        self.reference = reference
+
+    def __bool__(self):
+        return False
+
+
+class Variant:
+    """API shell with the reference's constructor signature (indelpost/variant.pyx:92)."""
+
+    def __init__(self, chrom, pos, ref, alt, reference, skip_validation=False):
+        raise NotImplementedError(_WHY % ("Variant", "indelpost/variant.pyx:62"))
+
+
+class VariantAlignment:
+    """API shell with the reference's constructor signature (indelpost/varaln.pyx:102-120)."""
+
+    def __init__(self, target, bam, window=50, exclude_duplicates=True, retarget_search_window=30,
+                 retarget_similarity_cutoff=0.7, exact_match_for_shiftable=True, mapping_quality_threshold=1,
+                 downsample_threshold=1000, base_quality_threshold=20, match_score=3, mismatch_penalty=2,
+                 gap_open_penalty=3, gap_extension_penalty=1, auto_adjust_extension_penalty=True, no_realignment=False):
+        raise NotImplementedError(_WHY % ("VariantAlignment", "indelpost/varaln.pyx:41"))
+
+
+class Contig:
+    """API shell with the reference's constructor signature (indelpost/contig.pyx:22)."""
+
+    def __init__(self, target, pileup, unspl_loc_ref, basequalthresh, mapqthresh, low_consensus_thresh=0.7, donwsample_lim=100):
+        raise NotImplementedError(_WHY % ("Contig", "indelpost/contig.pyx:19"))
+
+
+class FailedContig:
+    """API shell with the reference's constructor signature (indelpost/contig.pyx:354)."""
+
+    def __init__(self):
+        raise NotImplementedError(_WHY % ("FailedContig", "indelpost/contig.pyx:339"))

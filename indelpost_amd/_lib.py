@@ -34,7 +34,8 @@ EXPORTS = [
     "ssw_init", "init_destroy", "ssw_align", "align_destroy",
     # batched interface
     "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_set_routing", "ipx_upload",
-    "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch", "ipx_set_profiling",
+    "ipx_run", "ipx_sync", "ipx_download", "ipx_download_async", "ipx_wait", "ipx_set_async_io", "ipx_pin_host",
+    "ipx_unpin_host", "ipx_align_batch", "ipx_set_profiling",
     "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts",
     "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars",
 ]
@@ -121,6 +122,11 @@ def lib():
     L.ipx_run.argtypes = [vp]
     L.ipx_sync.argtypes = [vp]
     L.ipx_download.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
+    L.ipx_download_async.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
+    L.ipx_wait.argtypes = [vp]
+    L.ipx_set_async_io.argtypes = [vp, C.c_int]
+    L.ipx_pin_host.argtypes = [vp, i64]
+    L.ipx_unpin_host.argtypes = [vp]
     L.ipx_align_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, C.POINTER(i64)]
     L.ipx_set_profiling.argtypes = [vp, C.c_int]
     L.ipx_num_kernel_classes.restype = C.c_int
@@ -141,7 +147,8 @@ def lib():
     L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
     L.ipx_synth_mixed.restype = i64
     L.ipx_synth_mixed.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]
-    for f in ("ipx_set_params", "ipx_set_routing", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_align_batch",
+    for f in ("ipx_set_params", "ipx_set_routing", "ipx_upload", "ipx_run", "ipx_sync", "ipx_download", "ipx_download_async", "ipx_wait", "ipx_set_async_io", "ipx_pin_host",
+    "ipx_unpin_host", "ipx_align_batch",
               "ipx_set_profiling", "ipx_kernel_times"):
         getattr(L, f).restype = C.c_int
     _lib = L

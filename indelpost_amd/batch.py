@@ -275,6 +275,24 @@ class GpuAligner:
         self._check(rc, "ipx_download")
         return int(used.value)
 
+    def set_async_io(self, on=True):
+        """promise that the arrays of an uploaded JobTable stay alive and unchanged until the next sync(), so upload() does
+        not wait for its copies (the aligners keep a reference to the table they were given)"""
+        self._check(self._L.ipx_set_async_io(self._ctx, int(bool(on))), "ipx_set_async_io")
+
+    def download_async_into(self, rec, pool):
+        """after sync(): start the copy of the records and CIGAR ops into caller-owned buffers; wait() completes it.
+        Returns the number of CIGAR ops, or -(needed) when `pool` is too small (nothing is copied then)."""
+        used = C.c_int64(0)
+        rc = self._L.ipx_download_async(self._ctx, C.c_void_p(rec.ctypes.data), C.c_void_p(pool.ctypes.data), len(pool), C.byref(used))
+        if rc == -5 and used.value > len(pool):
+            return -int(used.value)
+        self._check(rc, "ipx_download_async")
+        return int(used.value)
+
+    def wait(self):
+        self._check(self._L.ipx_wait(self._ctx), "ipx_wait")
+
     def download(self, cigar_ops_per_job=16):
         n = self._n_jobs
         rec = np.zeros(n, RESULT_DTYPE)
@@ -368,10 +386,43 @@ class MultiStreamAligner:
         self.parts = [cls(device, match_score, mismatch_penalty, matrix) for _ in range(max(1, streams))]
         self.min_jobs_per_stream = 50000
         self._active = self.parts
+        self._pinned = []            # host arrays page-locked by pin_host (kept alive here)
+        self._out = None             # (records, cigar pool) reused across align() calls when pinned
 
     def close(self):
         for p in self.parts:
             p.close()
+        self.unpin()
+
+    # -- page-locked host buffers: transfers that overlap the other slices' kernels --
+    def pin_host(self, jobs, cigar_ops_per_job=16):
+        """Page-lock the arrays of `jobs` and a reusable pair of output buffers (hipHostRegister) and switch the contexts to
+        asynchronous transfers.  Worth it when the same host buffers are used for many batches (registering 150 MB costs
+        about as much as copying it once).  Returns False on back-ends without the capability (tests/emu)."""
+        L = getattr(self.parts[0], "_L", None)
+        if L is None or not hasattr(L, "ipx_pin_host"):
+            return False
+        self.unpin()
+        n = jobs.n_jobs
+        caps = sum(max(1024, (b1 - b0) * cigar_ops_per_job) for b0, b1 in zip(shard_bounds(n, len(self.parts))[:-1], shard_bounds(n, len(self.parts))[1:]))
+        out = (np.empty(n, RESULT_DTYPE), np.empty(caps, np.uint32))
+        for a in (jobs.reads, jobs.read_off, jobs.refs, jobs.ref_off, jobs.ref_id, jobs.gap_open, jobs.gap_ext, jobs.mask_len) + out:
+            if a is not None and a.nbytes and L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
+                self._pinned.append(a)
+        self._out = out
+        for p in self.parts:
+            p.set_async_io(True)
+        return True
+
+    def unpin(self):
+        L = getattr(self.parts[0], "_L", None) if self.parts else None
+        for a in self._pinned:
+            if L is not None:
+                L.ipx_unpin_host(C.c_void_p(a.ctypes.data))
+        self._pinned, self._out = [], None
+        for p in self.parts:
+            if hasattr(p, "set_async_io") and getattr(p, "_ctx", None):
+                p.set_async_io(False)
 
     def set_scoring(self, *a, **k):
         for p in self.parts:
@@ -426,11 +477,46 @@ class MultiStreamAligner:
         for p, j in zip(self._active, self._slices):               # slice i computes while slice i+1 is still uploading
             p.upload(j)
             p.run()
+        if self._out is not None and len(self._out[0]) == jobs.n_jobs and hasattr(self._active[0], "download_async_into"):
+            got = self._align_tail_async()
+            if got is not None:
+                return got
         try:
             self.sync()
         except IpxError:
             return merge_results([p.align(j) for p, j in zip(self._active, self._slices)])   # e.g. a slice outgrew its device cigar pool
         return self.download()
+
+    def _align_tail_async(self, cigar_ops_per_job=16):
+        """sync slice k, start its download into the pinned output buffers, go on to slice k+1: a slice's records travel while
+        the later slices still compute.  None when something did not fit (the caller falls back to the blocking path)."""
+        rec, pool = self._out
+        lo = pb = 0
+        try:
+            for p in self._active:
+                p.sync()
+                n = p._n_jobs
+                cap = max(1024, n * cigar_ops_per_job)
+                if pb + cap > len(pool) or p.download_async_into(rec[lo:lo + n], pool[pb:pb + cap]) < 0:
+                    for q in self._active:
+                        q.wait()
+                    return None
+                p._dl = (lo, n, pb)
+                lo += n
+                pb += cap
+            for p in self._active:
+                p.wait()
+        except IpxError:
+            for q in self._active:
+                try:
+                    q.wait()
+                except IpxError:
+                    pass
+            return None
+        for p in self._active:
+            lo, n, pb = p._dl
+            rec["cigar_off"][lo:lo + n] += np.uint32(pb)
+        return BatchResult(rec, pool)
 
     def set_profiling(self, on):
         for p in self.parts:

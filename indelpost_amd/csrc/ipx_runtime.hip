@@ -61,6 +61,11 @@ struct ipx_ctx {
     int bias = 0, flag = 1, filters = 0, filterd = 0, score_size = 2;
     int routing = 0;                   // IPX_ROUTE_* (speed only)
     bool static_valid = false;         // the job lists of the static passes match the resident batch and the parameters
+    bool async_io = false;             // ipx_set_async_io: the caller keeps its input buffers valid and unchanged until the next
+                                       //   ipx_sync and its output buffers until ipx_wait, so no call waits for a copy
+    std::vector<int64_t> h_refp;       // host copies that outlive ipx_upload (their H2D copies are asynchronous)
+    std::vector<int32_t> h_rlen;
+    uint32_t h_used = 0;               // cigar ops of the last run (read back in ipx_sync)
     // resident batch
     int64_t n_jobs = 0;
     int32_t n_refs = 0;
@@ -277,8 +282,11 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     HIPCHK(hipSetDevice(c->device));
     const int64_t read_bytes = read_off[n_jobs], ref_bytes = ref_off[n_refs];
     // host-side geometry: packed (4-byte aligned, padded) window offsets and the batch maxima
-    std::vector<int64_t> refp((size_t)n_refs + 1);
-    std::vector<int32_t> rlen((size_t)n_refs + 1);
+    if (c->async_io) HIPCHK(hipStreamSynchronize(c->stream));   // (the previous upload's copies read h_refp / h_rlen)
+    std::vector<int64_t> &refp = c->h_refp;
+    std::vector<int32_t> &rlen = c->h_rlen;
+    refp.assign((size_t)n_refs + 1, 0);
+    rlen.assign((size_t)n_refs + 1, 0);
     IpxDims &d = c->dims;
     memset(&d, 0, sizeof d);
     c->static_valid = false;
@@ -326,8 +334,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         HIPCHK(hipMemcpyAsync(c->gap_ext.p, gap_ext, (size_t)n_jobs, hipMemcpyHostToDevice, s));
         if (mask_len) HIPCHK(hipMemcpyAsync(c->mask_len.p, mask_len, 4 * (size_t)n_jobs, hipMemcpyHostToDevice, s));
     }
-    // the staged copies above read pageable host memory: finish them before the vectors go away
-    HIPCHK(hipStreamSynchronize(s));
+    // without the caller's promise (ipx_set_async_io) the copies above may still be reading its buffers: finish them
+    if (!c->async_io) HIPCHK(hipStreamSynchronize(s));
     // re-pack the windows on the device (4-byte aligned starts, padded, codes sanitised)
     HipBackend be{c};
     const bool prof = c->profiling;
@@ -408,7 +416,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     b.cigar_cursor = cursor; b.status = status;
     b.plan_counts = c->ws.plan_tables;
     b.maxcol_scratch = c->maxcol.as<uint32_t>();
-    HIPCHK(hipStreamSynchronize(s));
+    if (!c->async_io) HIPCHK(hipStreamSynchronize(s));
     return IPX_OK;
 }
 
@@ -462,8 +470,11 @@ int ipx_sync(ipx_ctx *c)
         c->ev_next = 0;
     }
     if (c->n_jobs == 0) { c->runs_since_sync = 0; return IPX_OK; }
-    uint32_t st = 0;
-    HIPCHK(hipMemcpy(&st, c->batch.status, 4, hipMemcpyDeviceToHost));
+    uint32_t st = 0, cur_st[8] = {0};
+    // cursor (4 words) and status (4 words) are neighbours in the small-table buffer: one read-back for both
+    HIPCHK(hipMemcpy(cur_st, c->batch.cigar_cursor, sizeof cur_st, hipMemcpyDeviceToHost));
+    c->h_used = cur_st[0];
+    st = cur_st[4];
     if (c->stats_dev) {
         HIPCHK(hipMemcpy(c->prev_tiles, c->stats_dev, sizeof c->prev_tiles, hipMemcpyDeviceToHost));
         c->prev_valid = true;
@@ -497,6 +508,49 @@ int ipx_download(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t ciga
         if (!cigar_pool || (int64_t)used > cigar_cap) { set_err("cigar pool of %lld ops is too small, %u needed", (long long)cigar_cap, used); return IPX_ERR_CIGAR_POOL; }
         HIPCHK(hipMemcpy(cigar_pool, c->cigar_pool.p, 4 * (size_t)used, hipMemcpyDeviceToHost));
     }
+    return IPX_OK;
+}
+
+int ipx_set_async_io(ipx_ctx *c, int on)
+{
+    if (!c) { set_err("ipx_set_async_io: null context"); return IPX_ERR_ARG; }
+    c->async_io = on != 0;
+    return IPX_OK;
+}
+
+int ipx_pin_host(void *p, int64_t bytes)
+{
+    if (!p || bytes <= 0) { set_err("ipx_pin_host: bad argument"); return IPX_ERR_ARG; }
+    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { set_err("hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); return IPX_ERR_NO_DEVICE; }
+    return IPX_OK;
+}
+
+int ipx_unpin_host(void *p)
+{
+    if (!p) return IPX_ERR_ARG;
+    return hipHostUnregister(p) == hipSuccess ? IPX_OK : IPX_ERR_NO_DEVICE;
+}
+
+// After ipx_sync: start copying the records and the CIGAR ops of the last run into the caller's buffers on the context's
+// stream and return; ipx_wait completes it.  (With pinned buffers the copy runs beside the other contexts' kernels.)
+int ipx_download_async(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t cigar_cap, int64_t *n_cigar_ops)
+{
+    if (!c || (c->n_jobs > 0 && !out)) { set_err("ipx_download_async: bad argument"); return IPX_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t used = c->n_jobs > 0 ? c->h_used : 0;
+    if (n_cigar_ops) *n_cigar_ops = used;
+    if (used && (!cigar_pool || (int64_t)used > cigar_cap)) { set_err("cigar pool of %lld ops is too small, %u needed", (long long)cigar_cap, used); return IPX_ERR_CIGAR_POOL; }
+    if (c->n_jobs > 0) HIPCHK(hipMemcpyAsync(out, c->res.p, 32 * (size_t)c->n_jobs, hipMemcpyDeviceToHost, c->stream));
+    if (used) HIPCHK(hipMemcpyAsync(cigar_pool, c->cigar_pool.p, 4 * (size_t)used, hipMemcpyDeviceToHost, c->stream));
+    return IPX_OK;
+}
+
+int ipx_wait(ipx_ctx *c)
+{
+    if (!c) { set_err("ipx_wait: null context"); return IPX_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return IPX_OK;
 }
 
@@ -657,6 +711,15 @@ int64_t ipx_synth_mixed(uint64_t *state, int32_t n_windows, int32_t wl_lo, int32
     *state = st;
     return job;
 }
+
+// CIGAR letter -> BAM opcode (ssw.h:34; used by the header's to_cigar_int): index = ASCII code, 0 for everything that is
+// not one of MIDNSHP=X ('=' is 61, 'D' 68, 'H' 72, 'I' 73, 'M' 77, 'N' 78, 'P' 80, 'S' 83, 'X' 88)
+extern "C" const uint8_t encoded_ops[128] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 7, 0, 0,
+    0, 0, 0, 0, 2, 0, 0, 0, 5, 1, 0, 0, 0, 0, 3, 0, 6, 0, 0, 4, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+};
 
 // ---- the reference's four-call interface, executed on GPU 0 ---------------------------------------
 struct _profile {                                  // ssw.c:115-123 (fields this path needs)

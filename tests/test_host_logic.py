@@ -124,9 +124,26 @@ def test_multi_stream_aligner_matches_single(emu):
 
 
 def test_out_of_scope_shells_say_so():
-    for name in ("Variant", "VariantAlignment", "Contig"):
-        with pytest.raises(NotImplementedError):
-            getattr(ip, name)()
+    """the API names the reference exports (indelpost/__init__.py:1-8) exist with its constructor signatures"""
+    import inspect
+    assert list(inspect.signature(ip.Variant.__init__).parameters)[1:] == ["chrom", "pos", "ref", "alt", "reference", "skip_validation"]
+    va = inspect.signature(ip.VariantAlignment.__init__).parameters
+    assert list(va)[1:4] == ["target", "bam", "window"] and va["window"].default == 50 and va["match_score"].default == 3 and \
+        va["gap_open_penalty"].default == 3 and va["gap_extension_penalty"].default == 1 and va["downsample_threshold"].default == 1000
+    with pytest.raises(NotImplementedError):
+        ip.Variant("1", 100, "A", "AT", None)
+    with pytest.raises(NotImplementedError):
+        ip.VariantAlignment(None, None)
+    with pytest.raises(NotImplementedError):
+        ip.Contig(None, [], None, 20, 1)
+    with pytest.raises(NotImplementedError):
+        ip.FailedContig()
+
+    class Fa:
+        def fetch(self, c, a, b):
+            return "ACGT"[a % 4:a % 4 + 1]
+    nv = ip.NullVariant("1", 7, Fa())
+    assert not nv and nv.ref == nv.alt == "G" and nv.pos == 7
 
 
 def test_shard_paths_keep_every_job_intact():
