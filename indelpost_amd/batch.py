@@ -61,12 +61,17 @@ class JobTable:
         self.ref_off = np.ascontiguousarray(ref_off, np.int64)
         self.ref_id = np.ascontiguousarray(ref_id, np.int32)
         n = len(self.ref_id)
-        # Python ints narrow to uint8 at the C boundary (ssw.h:129-130)
-        self.gap_open = np.ascontiguousarray(np.broadcast_to(np.asarray(gap_open, np.int64) & 255, (n,)), np.uint8)
-        self.gap_ext = np.ascontiguousarray(np.broadcast_to(np.asarray(gap_ext, np.int64) & 255, (n,)), np.uint8)
+        self.gap_open, self.gap_ext = self._narrow(gap_open, n), self._narrow(gap_ext, n)
         self.mask_len = None if mask_len is None else np.ascontiguousarray(mask_len, np.int32)
         if len(self.read_off) != n + 1:
             raise ValueError("read_off must have n_jobs+1 entries")
+
+    @staticmethod
+    def _narrow(g, n):
+        """Python ints narrow to uint8 at the C boundary (ssw.h:129-130); arrays that already are uint8 pass through"""
+        if isinstance(g, np.ndarray) and g.dtype == np.uint8 and g.shape == (n,) and g.flags.c_contiguous:
+            return g
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(g, np.int64) & 255, (n,)), np.uint8)
 
     @property
     def n_jobs(self):
@@ -473,8 +478,10 @@ class MultiStreamAligner:
         k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
         b = shard_bounds(jobs.n_jobs, k)
         self._active = self.parts[:k]
-        self._slices = [jobs.shard(b[i], b[i + 1]) for i in range(k)]
-        for p, j in zip(self._active, self._slices):               # slice i computes while slice i+1 is still uploading
+        self._slices = []
+        for i, p in enumerate(self._active):                       # slice i computes while slice i+1 is still being cut and uploaded
+            j = jobs.shard(b[i], b[i + 1])
+            self._slices.append(j)
             p.upload(j)
             p.run()
         if self._out is not None and len(self._out[0]) == jobs.n_jobs and hasattr(self._active[0], "download_async_into"):

@@ -135,6 +135,8 @@ def test_gpu_overhang_and_perfect_match_jobs(gpu, oracle_mod, port):
         else:
             st = int(rng.integers(1400, 1500))
             src = genome[st:st + 100]
+            if i % 4 == 0:
+                src = src[:50] + src[53:]                # a genomic read with a 3 bp deletion: one gap, not ruled out by alignment alone
         r = list(src)
         for k in np.flatnonzero(rng.random(len(r)) < 0.02):
             r[k] = LET[int(rng.integers(0, 4))]
