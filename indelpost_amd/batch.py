@@ -395,9 +395,9 @@ class MultiStreamAligner:
         self._out = None             # (records, cigar pool) reused across align() calls when pinned
 
     def close(self):
+        self.unpin()
         for p in self.parts:
             p.close()
-        self.unpin()
 
     # -- page-locked host buffers: transfers that overlap the other slices' kernels --
     def pin_host(self, jobs, cigar_ops_per_job=16):
@@ -475,15 +475,28 @@ class MultiStreamAligner:
         return BatchResult(rec, pool)
 
     def align(self, jobs):
+        """upload + run + sync + download"""
+        self.submit(jobs)
+        return self.collect()
+
+    def submit(self, jobs):
+        """Cut `jobs` into slices and enqueue, per slice, the copies in and the whole pipeline; returns without waiting.
+        collect() waits and fetches the results.  Two aligners used alternately (submit on one while collecting from the
+        other) keep the GPU busy across batches: bench_modes.run_end_to_end."""
         k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
         b = shard_bounds(jobs.n_jobs, k)
         self._active = self.parts[:k]
-        self._slices = []
-        for i, p in enumerate(self._active):                       # slice i computes while slice i+1 is still being cut and uploaded
+        self._submitted = jobs
+
+        def one(i):                                                # cut, enqueue the copies of and launch slice i
             j = jobs.shard(b[i], b[i + 1])
-            self._slices.append(j)
-            p.upload(j)
-            p.run()
+            self._active[i].upload(j)
+            self._active[i].run()
+            return j
+        self._slices = [one(i) for i in range(k)]                  # slice i computes while slice i+1 is still being cut and uploaded
+
+    def collect(self):
+        jobs = self._submitted
         if self._out is not None and len(self._out[0]) == jobs.n_jobs and hasattr(self._active[0], "download_async_into"):
             got = self._align_tail_async()
             if got is not None:
