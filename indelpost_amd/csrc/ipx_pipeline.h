@@ -258,10 +258,27 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             if (b.n_jobs <= fuse_max && per_have >= 1) {
                 const int per = per_want < per_have ? per_want : per_have;
                 be.launch(IPX_KEY(IPX_K_TRACEBACK, 9), k_tb_fast_all, 7 * per, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
-                          (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per);
+                          (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per, 0);
             } else {
-            IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3) IPX_TBF_LAUNCH(4)
-            IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
+                // widths 1..3 (nearly every job): their own launches, direction words in LDS when the rows fit
+                if (ipx_tbf_words_in_lds(rowcap) && !(routing & IPX_ROUTE_TB_NO_LDS_WORDS)) {
+#define IPX_TBF_LAUNCH_LDS(BW)                                                                                    \
+    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW, true>, ws.tbf_waves, 64, ipx_tbf_lds_bytes() + rowcap * 256, b, \
+              (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
+              rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n);
+            IPX_TBF_LAUNCH_LDS(1) IPX_TBF_LAUNCH_LDS(2) IPX_TBF_LAUNCH_LDS(3)
+#undef IPX_TBF_LAUNCH_LDS
+                } else {
+            IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3)
+                }
+                // widths 4..7 (rare): side by side in one launch
+                const int per = (ws.tbf_waves + 7) / 8 > 0 ? (ws.tbf_waves + 7) / 8 : 1;
+                if (!(routing & IPX_ROUTE_TB_NO_FUSE) && 4 * per <= ws.tbf_waves)   // (direction-word regions are indexed by block id)
+                    be.launch(IPX_KEY(IPX_K_TRACEBACK, 10), k_tb_fast_all, 4 * per, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
+                              (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per, 3);
+                else {
+            IPX_TBF_LAUNCH(4) IPX_TBF_LAUNCH(5) IPX_TBF_LAUNCH(6) IPX_TBF_LAUNCH(7)
+                }
             }
 #undef IPX_TBF_LAUNCH
             // everything else: one wavefront per job

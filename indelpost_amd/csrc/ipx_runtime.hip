@@ -596,7 +596,7 @@ const char *ipx_kernel_class_name(int k)
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else if (sub >= IPX_SLOW_BASE) snprintf(buf, sizeof buf, "%s_slowgap_s%d", k_names[kc], sub - IPX_SLOW_BASE);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
-    } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
+    } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub == 10) snprintf(buf, sizeof buf, "%s_fast_bw4to7", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
     else snprintf(buf, sizeof buf, "%s", k_names[kc]);
     return buf;
 }
