@@ -128,7 +128,7 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
  * variant they disable has an exact fallback -- which is what the test suite uses them for:
  *   1 no 16-bit pass before the 8-bit one    2 LDS-staged profile instead of register selectors
  *   4 no upper-bound (bracket) stage         8 one traceback launch per band width
- *  16 column maxima in global scratch instead of LDS         32 fast-traceback direction words in global scratch */
+ *  16 column maxima in global scratch instead of LDS */
 int ipx_set_routing(ipx_ctx *c, int flags);
 
 /* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,

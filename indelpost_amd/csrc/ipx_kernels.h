@@ -1090,9 +1090,6 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
 // ------------------------------------------------------------------------------------------------
 #define IPX_TBF_CIG 32
 static inline int ipx_tbf_lds_bytes() { return 64 + IPX_TBF_CIG * 256; }
-// direction words in LDS (32-bit words: first bands 1..3) while three blocks per CU still fit
-#define IPX_TBF_LDSW_MAX (52 * 1024)
-static inline bool ipx_tbf_words_in_lds(int rowcap) { return ipx_tbf_lds_bytes() + rowcap * 256 <= IPX_TBF_LDSW_MAX; }
 IPX_HD size_t ipx_tbf_scratch_bytes_per_block(int rowcap) { return (size_t)rowcap * 512; }   // sized for 64-bit words
 template <int BW> struct IpxTbWord { typedef uint32_t type; };
 template <> struct IpxTbWord<4> { typedef uint64_t type; };
@@ -1102,9 +1099,7 @@ template <> struct IpxTbWord<7> { typedef uint64_t type; };
 
 // (body shared by the per-width kernels and the all-widths kernel below: `bid` of `gdim` blocks work on this list,
 //  `scratch_bid` names the block's direction-word region)
-//  LDSW: the direction words of the block live in LDS behind the CIGAR buffer (room reserved by the launch: rowcap * 256 B,
-//  narrow bands only) instead of the global scratch: the walk back then waits ~64 cycles for a row instead of an L2 round trip
-template <int BW, bool LDSW = false>
+template <int BW>
 IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                           unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n, int bid, int gdim, int scratch_bid)
 {
@@ -1114,8 +1109,7 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
     unsigned char *lds = IPX_LDS_BASE;
     uint64_t *coltab = (uint64_t *)lds;                                 // [read letter a] -> bytes mat[c*5 + a], c = 0..4
     uint32_t *cig = (uint32_t *)(lds + 64) + lane;                      // [k*64]
-    word_t *dirw = (LDSW ? (word_t *)(lds + 64 + IPX_TBF_CIG * 256)
-                         : (word_t *)(dir_scratch + (size_t)scratch_bid * ipx_tbf_scratch_bytes_per_block(rowcap))) + lane;   // [row*64]
+    word_t *dirw = (word_t *)(dir_scratch + (size_t)scratch_bid * ipx_tbf_scratch_bytes_per_block(rowcap)) + lane;   // [row*64]
     if (lane < 5) {
         uint64_t t = 0;
         for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
@@ -1270,11 +1264,11 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
     }
 }
 
-template <int BW, bool LDSW = false>
+template <int BW>
 IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                                unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n)
 {
-    tb_fast_body<BW, LDSW>(b, list, list_n, rowcap, dir_scratch, next, next_n, (int)IPX_BID, (int)IPX_GDIM, (int)IPX_BID);
+    tb_fast_body<BW>(b, list, list_n, rowcap, dir_scratch, next, next_n, (int)IPX_BID, (int)IPX_GDIM, (int)IPX_BID);
 }
 
 // Several widths in ONE launch, `per` blocks each (block b serves width bw_first + b / per + 1).  The per-width launches

@@ -260,17 +260,10 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 be.launch(IPX_KEY(IPX_K_TRACEBACK, 9), k_tb_fast_all, 7 * per, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
                           (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per, 0);
             } else {
-                // widths 1..3 (nearly every job): their own launches, direction words in LDS when the rows fit
-                if (ipx_tbf_words_in_lds(rowcap) && !(routing & IPX_ROUTE_TB_NO_LDS_WORDS)) {
-#define IPX_TBF_LAUNCH_LDS(BW)                                                                                    \
-    be.launch(IPX_KEY(IPX_K_TRACEBACK, 1 + BW), k_tb_fast<BW, true>, ws.tbf_waves, 64, ipx_tbf_lds_bytes() + rowcap * 256, b, \
-              (const uint32_t *)(ws.tb_list + (int64_t)(BW - 1) * b.n_jobs), (const uint32_t *)(ws.tb_list_n + (BW - 1)),  \
-              rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n);
-            IPX_TBF_LAUNCH_LDS(1) IPX_TBF_LAUNCH_LDS(2) IPX_TBF_LAUNCH_LDS(3)
-#undef IPX_TBF_LAUNCH_LDS
-                } else {
+                // widths 1..3 (nearly every job): their own launches.  (Direction words in LDS instead of the global scratch were
+                // measured in r02 and dropped: 46 KB per one-wave block leaves 3 waves per CU, and the lane-per-job walk needs
+                // many waves in flight more than it needs short loads -- 4.0 ms against 2.6 ms per million jobs.)
             IPX_TBF_LAUNCH(1) IPX_TBF_LAUNCH(2) IPX_TBF_LAUNCH(3)
-                }
                 // widths 4..7 (rare): side by side in one launch
                 const int per = (ws.tbf_waves + 7) / 8 > 0 ? (ws.tbf_waves + 7) / 8 : 1;
                 if (!(routing & IPX_ROUTE_TB_NO_FUSE) && 4 * per <= ws.tbf_waves)   // (direction-word regions are indexed by block id)

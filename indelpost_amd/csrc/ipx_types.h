@@ -63,7 +63,6 @@ enum {
     IPX_ROUTE_NO_BRACKET = 4,      // no upper-bound stage: a read the lower-bound stage cannot settle goes to the stepped pass
     IPX_ROUTE_TB_NO_FUSE = 8,      // one traceback launch per band width even for small batches
     IPX_ROUTE_NO_MC_LDS = 16,      // column maxima in the global scratch even when they would fit in LDS
-    IPX_ROUTE_TB_NO_LDS_WORDS = 32,// direction words of the fast traceback in the global scratch even when they would fit in LDS
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels

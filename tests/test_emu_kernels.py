@@ -154,7 +154,7 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
         assert res.as_dict(i) == port.align(reads[i], w, mat, 3, 1, mask_len=masks[i]), i
 
 
-@pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE, R.ROUTE_TB_NO_LDS_WORDS),
+@pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE),
                                    (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE)])
 def test_emu_routing_knobs_off(emu, golden_c, knobs):
     """The speed-only routing decisions (the upper-bound stage, 16-bit pass first, register-selector profile, column
