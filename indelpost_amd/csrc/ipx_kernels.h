@@ -199,24 +199,38 @@ IPX_DEV void plan_note(const IpxBatch &b, int key)
     }
 }
 
-// Jobs of a wave that fall into the same class share ONE atomic: the wave's first lane of the class
-// adds the population count, every lane derives its slot from its rank in the ballot.
-IPX_DEV uint32_t wave_class_slot(uint32_t *counter, int cls)
+// Slots in per-class lists for IPX_PLAN_ROUNDS jobs per lane at once: ONE atomic per distinct class for all 64 *
+// IPX_PLAN_ROUNDS jobs of the wave (r02: with one wave per block and one round per atomic, a million jobs of a single class meant 15 600 atomics on
+// one address -- 0.2 to 0.8 ms of pure serialisation per planner launch).  Slots go round by round, lane by lane.
+#define IPX_PLAN_ROUNDS 8
+IPX_DEV void wave_class_slots(uint32_t *counter, const int (&cls)[IPX_PLAN_ROUNDS], uint32_t (&slot)[IPX_PLAN_ROUNDS])
 {
     const int lane = lane_id();
-    uint32_t slot = 0;
-    uint64_t todo = xl_ballot(cls >= 0);
-    while (todo) {                                         // one round per distinct class in the wave
-        const int leader = __builtin_ffsll((long long)todo) - 1;
-        const int c = (int)xl_shfl((uint32_t)cls, leader);
-        const uint64_t m = xl_ballot(cls == c);
+    uint64_t todo[IPX_PLAN_ROUNDS];
+    bool any = false;
+    IPX_UNROLL
+    for (int r = 0; r < IPX_PLAN_ROUNDS; ++r) { todo[r] = xl_ballot(cls[r] >= 0); any = any || todo[r] != 0; slot[r] = 0; }
+    while (any) {                                          // one iteration per distinct class in the wave's jobs
+        int c = -1;
+        IPX_UNROLL
+        for (int r = IPX_PLAN_ROUNDS - 1; r >= 0; --r)
+            if (todo[r]) c = (int)xl_shfl((uint32_t)cls[r], __builtin_ffsll((long long)todo[r]) - 1);
+        uint64_t m[IPX_PLAN_ROUNDS];
+        uint32_t total = 0;
+        IPX_UNROLL
+        for (int r = 0; r < IPX_PLAN_ROUNDS; ++r) { m[r] = xl_ballot(cls[r] == c); total += (uint32_t)__builtin_popcountll(m[r]); }
         uint32_t base = 0;
-        if (lane == leader) base = atomic_add_u32(&counter[c], (uint32_t)__builtin_popcountll(m));
-        base = xl_shfl(base, leader);
-        if (cls == c) slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        todo &= ~m;
+        if (lane == 0) base = atomic_add_u32(&counter[c], total);
+        base = xl_first(base);
+        any = false;
+        IPX_UNROLL
+        for (int r = 0; r < IPX_PLAN_ROUNDS; ++r) {
+            if (cls[r] == c) slot[r] = base + (uint32_t)__builtin_popcountll(m[r] & ((1ull << lane) - 1ull));
+            base += (uint32_t)__builtin_popcountll(m[r]);
+            todo[r] &= ~m[r];
+            any = any || todo[r] != 0;
+        }
     }
-    return slot;
 }
 
 // Planner kernels are ONE wave per block and a handful of registers: on a GPU busy with other streams' DP blocks (which
@@ -230,12 +244,18 @@ IPX_DEV uint32_t wave_class_slot(uint32_t *counter, int cls)
 // pass whose jobs come straight from k_init (16-bit only profiles)
 IPX_KERNEL void k_plan_count(IpxBatch b, int pass)
 {
-    const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
-    const int64_t rounds = (b.n_jobs + stride - 1) / stride;
-    for (int64_t q = 0; q < rounds; ++q) {                 // every lane runs every round (wave-wide ballots)
-        const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
-        const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
-        plan_note(b, cls >= 0 ? pass * 256 + cls : -1);
+    const int64_t chunk = (int64_t)IPX_BDIM * IPX_PLAN_ROUNDS, stride = (int64_t)IPX_GDIM * chunk;
+    const int64_t iters = (b.n_jobs + stride - 1) / stride;
+    uint32_t *row = b.plan_counts + (size_t)pass * (2 * IPX_NUM_CLASSES);
+    for (int64_t q = 0; q < iters; ++q) {                  // every lane runs every iteration (wave-wide ballots)
+        int cls[IPX_PLAN_ROUNDS];
+        uint32_t slot[IPX_PLAN_ROUNDS];
+        IPX_UNROLL
+        for (int r = 0; r < IPX_PLAN_ROUNDS; ++r) {
+            const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)r * IPX_BDIM + IPX_TID;
+            cls[r] = i < b.n_jobs ? plan_class(b, pass, i) : -1;
+        }
+        wave_class_slots(row, cls, slot);                  // (the slots are not needed here, the sums are)
     }
 }
 
@@ -277,16 +297,25 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass, int na)
         }
     }
     IPX_SYNC();
-    const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
-    const int64_t rounds = (b.n_jobs + stride - 1) / stride;
-    for (int64_t q = 0; q < rounds; ++q) {
-        const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
-        const int cls = i < b.n_jobs ? plan_class(b, pass, i) : -1;
-        const uint32_t pos = wave_class_slot(p.cursor, cls);
-        if (cls >= 0) {
-            // (a job the counting side missed would run past its class: refuse it instead)
-            if (pos >= cls_off[cls + 1] - cls_off[cls]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
-            else p.perm[cls_off[cls] + pos] = (uint32_t)i;
+    const int64_t chunk = (int64_t)IPX_BDIM * IPX_PLAN_ROUNDS, stride = (int64_t)IPX_GDIM * chunk;
+    const int64_t iters = (b.n_jobs + stride - 1) / stride;
+    for (int64_t q = 0; q < iters; ++q) {
+        int cls[IPX_PLAN_ROUNDS];
+        uint32_t pos[IPX_PLAN_ROUNDS];
+        IPX_UNROLL
+        for (int r = 0; r < IPX_PLAN_ROUNDS; ++r) {
+            const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)r * IPX_BDIM + IPX_TID;
+            cls[r] = i < b.n_jobs ? plan_class(b, pass, i) : -1;
+        }
+        wave_class_slots(p.cursor, cls, pos);
+        IPX_UNROLL
+        for (int r = 0; r < IPX_PLAN_ROUNDS; ++r) {
+            const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)r * IPX_BDIM + IPX_TID;
+            if (cls[r] >= 0) {
+                // (a job the counting side missed would run past its class: refuse it instead)
+                if (pos[r] >= cls_off[cls[r] + 1] - cls_off[cls[r]]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
+                else p.perm[cls_off[cls[r]] + pos[r]] = (uint32_t)i;
+            }
         }
     }
 }
@@ -1054,23 +1083,32 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
 #define IPX_TBF_MAXBW 7
 IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc)
 {
-    const int64_t stride = (int64_t)IPX_GDIM * IPX_BDIM;
-    const int64_t rounds = (b.n_jobs + stride - 1) / stride;
-    for (int64_t q = 0; q < rounds; ++q) {                 // every lane runs every round (wave-wide ballots)
-        const int64_t i = q * stride + (int64_t)IPX_BID * IPX_BDIM + IPX_TID;
-        int cls = -1;
-        if (i < b.n_jobs) {
-            const IpxResult r = b.res[i];
-            if (cigar_needed(b, r)) {
-                const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
-                const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-                cls = bw <= IPX_TBF_MAXBW ? bw - 1 : IPX_TBF_MAXBW;
+    const int64_t chunk = (int64_t)IPX_BDIM * IPX_PLAN_ROUNDS, stride = (int64_t)IPX_GDIM * chunk;
+    const int64_t iters = (b.n_jobs + stride - 1) / stride;
+    for (int64_t q = 0; q < iters; ++q) {                  // every lane runs every iteration (wave-wide ballots)
+        int cls[IPX_PLAN_ROUNDS];
+        uint32_t slot[IPX_PLAN_ROUNDS];
+        IPX_UNROLL
+        for (int k = 0; k < IPX_PLAN_ROUNDS; ++k) {
+            const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)k * IPX_BDIM + IPX_TID;
+            cls[k] = -1;
+            if (i < b.n_jobs) {
+                const IpxResult r = b.res[i];
+                if (cigar_needed(b, r)) {
+                    const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
+                    const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+                    cls[k] = bw <= IPX_TBF_MAXBW ? bw - 1 : IPX_TBF_MAXBW;
+                }
             }
         }
-        const uint32_t slot = wave_class_slot(counters, cls);
-        if (cls >= 0) {
-            if (cls < IPX_TBF_MAXBW) lists[(int64_t)cls * b.n_jobs + slot] = (uint32_t)i;
-            else esc[slot] = (uint32_t)i;
+        wave_class_slots(counters, cls, slot);
+        IPX_UNROLL
+        for (int k = 0; k < IPX_PLAN_ROUNDS; ++k) {
+            const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)k * IPX_BDIM + IPX_TID;
+            if (cls[k] >= 0) {
+                if (cls[k] < IPX_TBF_MAXBW) lists[(int64_t)cls[k] * b.n_jobs + slot[k]] = (uint32_t)i;
+                else esc[slot[k]] = (uint32_t)i;
+            }
         }
     }
 }

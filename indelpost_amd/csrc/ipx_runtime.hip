@@ -131,10 +131,10 @@ struct HipBackend {
         const int64_t g = sized(t), cap = (int64_t)c->num_cu * 8;
         return (int)(c->prev_valid ? g : (g < cap ? g : cap));
     }
-    // planner kernels: one wave per block, four jobs per lane
+    // planner kernels: one wave per block, IPX_PLAN_ROUNDS jobs per lane and iteration
     int plan_grid(int64_t n) const
     {
-        int64_t g = (n + 255) / 256;
+        int64_t g = (n + 64 * IPX_PLAN_ROUNDS - 1) / (64 * IPX_PLAN_ROUNDS);
         if (g < 1) g = 1;
         const int64_t cap = (int64_t)c->num_cu * 16;
         return (int)(g < cap ? g : cap);
