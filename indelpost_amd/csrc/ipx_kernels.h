@@ -1137,10 +1137,18 @@ template <> struct IpxTbWord<7> { typedef uint64_t type; };
 
 // (body shared by the per-width kernels and the all-widths kernel below: `bid` of `gdim` blocks work on this list,
 //  `scratch_bid` names the block's direction-word region)
-template <int BW>
+// WIDEN: a job whose band has to double (max < score, ssw.c:669) is handed to the list of width 2*BW -- served by a LATER
+// launch of this same lane-per-job kernel -- instead of the one-wave-per-job kernel, as long as 2*BW <= 7.  A list entry
+// with bit 31 set is such a second (third) band iteration: its first band was narrower than BW.  The doubled run starts
+// from fresh direction words, the reference from the words the narrower iterations left behind; the two differ only if
+// the walk back reads a cell the current iteration has not written, so a retried job that meets such a cell goes to the
+// general kernel (which keeps the reference's buffer across iterations) instead of reporting the failure itself.
+template <int BW, bool WIDEN>
 IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                           unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n, int bid, int gdim, int scratch_bid)
 {
+    uint32_t *lists_base = (uint32_t *)list - (int64_t)(BW - 1) * b.n_jobs;   // list BW-1 of the seven per-width lists
+    uint32_t *counters = next_n - IPX_TBF_MAXBW;                              // their counters (the eighth is next_n)
     constexpr int WD = 2 * BW + 1, W = 2 * BW + 3;
     typedef typename IpxTbWord<BW>::type word_t;
     const int lane = lane_id();
@@ -1159,7 +1167,9 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
     for (int64_t base = (int64_t)bid * 64; base < (int64_t)n; base += (int64_t)gdim * 64) {
         const int64_t li = base + lane;
         if (li >= (int64_t)n) continue;
-        const int64_t jb = list[li];
+        const uint32_t ent = list[li];
+        const int64_t jb = ent & 0x7FFFFFFFu;
+        const bool retried = (ent >> 31) != 0;                        // a doubled band: the first band was narrower
         IpxResult r = b.res[jb];
         const int rid = b.ref_id[jb];
         const int fullRef = b.ref_len[rid];
@@ -1172,7 +1182,8 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
         const int score = r.score1;
         const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
         const int len = refLen > readLen ? refLen : readLen;
-        bool esc = bw != BW || readLen > rowcap;
+        bool esc = (!retried && bw != BW) || readLen > rowcap;
+        bool widen = false;
         int mx = 0;
         if (!esc) {
             int hb[W + 1], eb[W + 1], hc[W + 1];                        // fresh arrays (ssw.c:607-609, 627)
@@ -1245,11 +1256,13 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
                 IPX_UNROLL
                 for (int q = 1; q <= WD; ++q) if (q <= nact) hb[q] = hc[q];   // ssw.c:666
             }
-            if (mx < score && BW * 2 <= len) esc = true;                // band would double (ssw.c:668-669)
+            if (mx < score && BW * 2 <= len) {                          // band would double (ssw.c:668-669)
+                if (WIDEN && 2 * BW <= IPX_TBF_MAXBW) widen = true; else esc = true;
+            }
         }
         int lcnt = 0, e = 0, op = 0;
         bool fail = false;
-        if (!esc) {
+        if (!esc && !widen) {
             // ---- trace back (ssw.c:673-751) ----
             // the walk moves up one row at most per step: keep the words of rows i and i-1 in registers and
             // fetch row i-2 as soon as the walk moves (a cell index outside those two rows reads memory)
@@ -1289,6 +1302,12 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
                 }
             }
         }
+        if (widen) {
+            constexpr int NB = 2 * BW <= IPX_TBF_MAXBW ? 2 * BW : IPX_TBF_MAXBW;
+            lists_base[(int64_t)(NB - 1) * b.n_jobs + atomic_add_u32(&counters[NB - 1], 1u)] = (uint32_t)jb | 0x80000000u;
+            continue;
+        }
+        if (fail && retried) esc = true;                               // (see WIDEN above)
         if (esc) { next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb; continue; }
         if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; continue; }                // ssw.c:911
         if (op == 0) { ++lcnt; cig[(lcnt - 1) * 64] = ((uint32_t)(e + 1) << 4); }          // ssw.c:734-751
@@ -1306,7 +1325,7 @@ template <int BW>
 IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                                unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n)
 {
-    tb_fast_body<BW>(b, list, list_n, rowcap, dir_scratch, next, next_n, (int)IPX_BID, (int)IPX_GDIM, (int)IPX_BID);
+    tb_fast_body<BW, true>(b, list, list_n, rowcap, dir_scratch, next, next_n, (int)IPX_BID, (int)IPX_GDIM, (int)IPX_BID);
 }
 
 // Several widths in ONE launch, `per` blocks each (block b serves width bw_first + b / per + 1).  The per-width launches
@@ -1320,13 +1339,13 @@ IPX_KERNEL_WAVE void k_tb_fast_all(IpxBatch b, const uint32_t *lists, const uint
     const int bid = (int)IPX_BID, bw = bw_first + bid / per, loc = bid % per;
     const uint32_t *list = lists + (int64_t)bw * b.n_jobs, *cnt = counters + bw;
     switch (bw) {
-    case 0: tb_fast_body<1>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
-    case 1: tb_fast_body<2>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
-    case 2: tb_fast_body<3>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
-    case 3: tb_fast_body<4>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
-    case 4: tb_fast_body<5>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
-    case 5: tb_fast_body<6>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
-    default: tb_fast_body<7>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 0: tb_fast_body<1, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 1: tb_fast_body<2, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 2: tb_fast_body<3, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 3: tb_fast_body<4, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 4: tb_fast_body<5, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    case 5: tb_fast_body<6, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
+    default: tb_fast_body<7, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, per, bid); break;
     }
 }
 

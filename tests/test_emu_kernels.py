@@ -252,3 +252,30 @@ def test_emu_slow_gap_jobs_are_a_class_of_their_own(emu, oracle_mod, port):
     assert any(c < SLOW_BASE for c in wf) and any(c >= SLOW_BASE for c in wf)     # 150 bp reads: fast and slow classes side by side
     low = _launched(a, K_BYTE_LOW)
     assert any(c < SLOW_BASE for c in low) and any(c >= SLOW_BASE for c in low)   # 60 bp reads likewise
+
+
+def test_emu_band_doubling_stays_in_the_lane_per_job_kernels(emu, oracle_mod, port):
+    """Compensating indels (net length change 0..2, path wandering 2..4 diagonals away): the first band fails (max < score,
+    ssw.c:669) and doubles once or twice.  With one launch per band width the doubled run is served by the wider
+    lane-per-job kernel; with everything fused (small batch, default) by the general kernel: same CIGARs, equal to the oracle."""
+    rng = np.random.default_rng(77)
+    w = rng.integers(0, 4, 320).astype(np.int8)
+    reads = []
+    for i in range(12):
+        st = int(rng.integers(0, 120))
+        r = w[st:st + 150].copy()
+        a, b2 = 40 + i, 100 + i
+        k = 1 + i % 4                                             # insert k bases at a, delete k (or k-1) bases at b2
+        r = np.concatenate([r[:a], rng.integers(0, 4, k).astype(np.int8), r[a:b2], r[b2 + k - (i % 2):]])
+        reads.append(r)
+    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), [3, 2, 1, 3] * 3, [1, 0, 0, 0] * 3, encoded=True)
+    mat = oracle_mod.dna_matrix(3, 2)
+    exp = [port.align(r, w, mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])) for i, r in enumerate(reads)]
+    assert sum(1 for e in exp if e["cigar"] and sum(1 for c in e["cigar"] if c & 15) >= 2) >= 6      # both indels recovered
+    for routing in (R.ROUTE_TB_NO_FUSE, 0):
+        a = emu(0, 3, 2)
+        a.set_routing(routing)
+        res = a.align(jobs)
+        assert a.status == 0
+        for i in range(len(reads)):
+            assert res.as_dict(i) == exp[i], (routing, i)
