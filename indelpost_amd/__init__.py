@@ -7,6 +7,8 @@ reference exports from ``indelpost/__init__.py`` that lie outside that path (``V
 from .sswpy import SSW, Alignment, force_align, format_force_align          # noqa: F401
 from .localn import (make_aligner, align, align_pileup, realign_pileup_jobs, classify_realigned, find_targets_by_ssw,  # noqa: F401
                      is_covering_target, is_compatible_repeats)
+from .pileup import (split_cigar, trim_ref_flank, update_cigar, update_read_positions, update_read_info_realn,  # noqa: F401
+                     update_reads_batch)
 from .cigar import findall_indels, make_insertion_first, merge_consecutive_gaps, to_minimal_repeat_unit  # noqa: F401
 from .retarget import (generate_grid, retarget_jobs, grid_align, indel_candidates, get_local_reference,  # noqa: F401
                        UnsplicedLocalReference, overhang_jobs, overhang_alignment_verdicts, perfect_match_batch)

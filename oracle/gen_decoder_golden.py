@@ -38,13 +38,16 @@ def function_text(path, name):
 
 
 def strip_cython_types(src):
-    """`cdef int f(str a, int b):` -> `def f(a, b):`; `cdef T x = e` -> `x = e`; bare `cdef T x` declarations dropped"""
-    types = r"(?:str|int|bint|list|tuple|dict|object)"
+    """`cdef int f(str a, int b):` -> `def f(a, b):` (typed parameters on one line or one per line); `cdef T x = e` ->
+    `x = e`; bare `cdef T x[, y]` declarations dropped.  Statements are left as they are."""
+    types = r"(?:str|int|bint|list|tuple|dict|object|double|float)"
     out = []
     for line in src.split("\n"):
-        line = re.sub(r"^(?:cdef|cpdef) %s (\w+)\(" % types, r"def \1(", line)
+        if re.match(r"^(?:cdef|cpdef) %s \w+\s*\(" % types, line):
+            line = re.sub(r"^(?:cdef|cpdef) %s (\w+\s*\()" % types, r"def \1", line)
+            line = re.sub(r"(?<=[(,])\s*%s\s+(?=\w)" % types, " ", line).replace("( ", "(")
         line = re.sub(r"^(\s+)%s (\w+,?)\s*$" % types, r"\1\2", line)                     # one typed parameter per line
-        m = re.match(r"^(\s+)cdef %s (\w+)( = .*)?$" % types, line)
+        m = re.match(r"^(\s+)cdef %s (\w+(?:\s*,\s*\w+)*)( = .*)?$" % types, line)
         if m:
             line = (m.group(1) + m.group(2) + m.group(3)) if m.group(3) else ""
         out.append(line)
@@ -53,9 +56,10 @@ def strip_cython_types(src):
 
 def load_reference_functions():
     ns = {"re": re, "cigar_ptrn": re.compile(r"[0-9]+[MIDNSHPX=]")}
-    for fname, names in (("utilities.pyx", ["most_common", "to_minimal_repeat_unit", "merge_consecutive_gaps", "make_insertion_first"]),
+    for fname, names in (("utilities.pyx", ["most_common", "to_minimal_repeat_unit", "merge_consecutive_gaps", "make_insertion_first", "split_cigar"]),
                          ("localn.pyx", ["findall_indels", "is_compatible_repeats", "is_covering_target"]),
-                         ("varaln.pyx", ["generate_grid"])):
+                         ("varaln.pyx", ["generate_grid"]),
+                         ("pileup.pyx", ["trim_ref_flank", "numeric_span", "update_cigar", "update_read_positions"])):
         for n in names:
             exec(compile(strip_cython_types(function_text(os.path.join(REF, fname), n)), "<%s:%s>" % (fname, n), "exec"), ns)
     return ns
@@ -93,7 +97,7 @@ def main():
     mat = O.dna_matrix(3, 2)
     rng = np.random.default_rng(20260217)
     out = {"generator": "oracle/gen_decoder_golden.py", "cigar": [], "repeat_unit": [], "findall_indels": [], "compatible_repeats": [],
-           "covering_target": [], "grid": []}
+           "covering_target": [], "grid": [], "split_cigar": [], "trim_ref_flank": [], "update_cigar": [], "read_positions": []}
 
     for _ in range(300):                                          # CIGAR token shuffling
         toks = [str(int(rng.integers(1, 30))) + "MMMIDID"[int(rng.integers(0, 7))] for _ in range(int(rng.integers(1, 10)))]
@@ -164,6 +168,59 @@ def main():
     for cig in ("20M2I30M", "10M1D40M"):                          # a gapped CIGAR is never a covering alignment (localn.pyx:311-312)
         args = ["g", genome[:52], "AC", genome[100:130], "AC", genome[130:160], cig, 52, 0, 51, 0, 51, 0]
         out["covering_target"].append({"args": args, "expect": int(F["is_covering_target"](*args))})
+
+    def rand_cigar(with_n=False):
+        toks = [str(int(rng.integers(1, 40))) + "M"]
+        for _ in range(int(rng.integers(0, 5))):
+            toks.append(str(int(rng.integers(1, 9))) + ("IDN" if with_n else "ID")[int(rng.integers(0, 3 if with_n else 2))])
+            toks.append(str(int(rng.integers(1, 40))) + "M")
+        if rng.random() < 0.3:
+            toks = [str(int(rng.integers(1, 9))) + "S"] + toks
+        if rng.random() < 0.3:
+            toks.append(str(int(rng.integers(1, 9))) + "S")
+        return toks
+    for _ in range(250):                                          # split_cigar: cut a BAM CIGAR at a genome position
+        toks = rand_cigar(with_n=True)
+        start = int(rng.integers(100, 1000))
+        span = sum(int(t[:-1]) for t in toks if t[-1] not in "IHP")
+        tp = start + int(rng.integers(0, span))
+        res = F["split_cigar"]("".join(toks), tp, start)
+        out["split_cigar"].append({"cigar": "".join(toks), "target_pos": tp, "start": start, "expect": [list(res[0]), list(res[1])] if res else None})
+    for _ in range(80):
+        toks = rand_cigar()
+        flank = s(rng.integers(0, 4, int(rng.integers(0, 200))))
+        left = bool(rng.integers(0, 2))
+        out["trim_ref_flank"].append({"flank": flank, "cigar": toks, "left": left, "expect": F["trim_ref_flank"](flank, toks, left)})
+    for k in range(400):                                          # update_cigar: realigned flank CIGAR -> BAM CIGAR with clips and introns
+        left = k % 2 == 0
+        toks = [t for t in rand_cigar() if t[-1] != "S"]
+        if not left:
+            toks = [str(int(rng.integers(1, 9))) + "ID"[int(rng.integers(0, 2))]] + toks        # the indel itself leads the right flank
+        start = int(rng.integers(1000, 2000))
+        nspl = int(rng.choice([0, 0, 1, 2]))
+        spans, p = [], start + int(rng.integers(1, 30))
+        for _ in range(nspl):
+            a = p + int(rng.integers(0, 40))
+            b = a + int(rng.integers(20, 200))
+            spans.append("%d-%d" % (a, b))
+            p = b + 1 + int(rng.integers(5, 40))
+        ptrn = ":".join(spans)
+        spl = (ptrn, "") if left else ("", ptrn)
+        clipped = s(rng.integers(0, 4, int(rng.choice([0, 0, 3, 7]))))
+        res = F["update_cigar"]("".join(toks), list(toks), start, spl, clipped, left)
+        out["update_cigar"].append({"realn_cigar": toks, "start_pos": start, "splice": list(spl), "clipped": clipped, "left": left, "expect": list(res)})
+    for _ in range(80):
+        lt = rand_cigar(with_n=True)
+        rt = [str(int(rng.integers(1, 9))) + "ID"[int(rng.integers(0, 2))]] + [t for t in rand_cigar(with_n=True) if True]
+        if lt[-1][-1] == "S":
+            lt = lt[:-1]
+        if rt[1][-1] == "S":
+            rt = [rt[0]] + rt[2:]
+        read = {"lt_cigar": lt, "rt_cigar": rt}
+        tp = int(rng.integers(1000, 5000))
+        F["update_read_positions"](read, tp)
+        out["read_positions"].append({"lt_cigar": lt, "rt_cigar": rt, "target_pos": tp,
+                                      "expect": {k2: read[k2] for k2 in ("read_start", "read_end", "start_offset", "end_offset", "aln_start", "aln_end")}})
 
     class T:                                                      # generate_grid only reads len(target.indel_seq)
         def __init__(self, n):

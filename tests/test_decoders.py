@@ -143,3 +143,40 @@ def test_indel_candidates_filters():
     read2 = ref[3:40] + "GG" + ref[43:88]
     c2, cx2 = retarget.indel_candidates(aln2, read2, ref, 1000, "D", 1003, 1090, 50)
     assert cx2 is True and c2 == [(1039, ref[39:43], ref[39] + "GG")]
+
+
+def test_cigar_surgery_golden(gold):
+    """split_cigar / trim_ref_flank / update_cigar / update_read_positions (utilities.pyx:330-357, pileup.pyx:913-1048)
+    against the reference's own function bodies, incl. splice junctions re-inserted as N and soft clips"""
+    from indelpost_amd import pileup as P
+    for c in gold["split_cigar"]:
+        got = P.split_cigar(c["cigar"], c["target_pos"], c["start"])
+        assert (None if got is None else [list(got[0]), list(got[1])]) == c["expect"], c
+    for c in gold["trim_ref_flank"]:
+        assert P.trim_ref_flank(c["flank"], c["cigar"], c["left"]) == c["expect"], c
+    n_with_n = 0
+    for c in gold["update_cigar"]:
+        got = P.update_cigar("", list(c["realn_cigar"]), c["start_pos"], tuple(c["splice"]), c["clipped"], c["left"])
+        assert got == c["expect"], c
+        n_with_n += any(t.endswith("N") for t in got)
+    assert n_with_n > 40
+    for c in gold["read_positions"]:
+        read = {"lt_cigar": c["lt_cigar"], "rt_cigar": c["rt_cigar"]}
+        P.update_read_positions(read, c["target_pos"])
+        assert {k: read[k] for k in c["expect"]} == c["expect"], c
+
+
+def test_update_read_info_realn_known_answer():
+    """the realignment branch of update_read_info (pileup.pyx:847-911) on the 5M1D11M KAT of SURVEY 8c, hand-derived"""
+    from indelpost_amd import pileup as P
+    ref, seq = "ACGTACGTTTGACCAGT", "ACGTAGTTTGACCAGT"
+    read = {"read_seq": seq, "read_qual": list(range(16)), "cigar_string": "16M", "read_start": 1001, "splice_pattern": ("", "")}
+    aln = Alignment("5M1D11M", 45, 3, 0, 16, 0, 15)
+    out = P.update_read_info_realn(read, aln, ref, 1001, 1005, "", False, lambda p, r, a: (p, r, a) == (1005, "AC", "A"))
+    assert out["cigar_updated"] and out["is_target"] and out["cigar_string"] == "5M1D11M" and out["cigar_list"] == ["5M", "1D", "11M"]
+    assert out["lt_flank"] == "ACGTA" and out["rt_flank"] == "GTTTGACCAGT" and out["indel_seq"] == ""
+    assert out["lt_ref"] == "ACGTA" and out["rt_ref"] == "GTTTGACCAGT" and out["lt_qual"] == [0, 1, 2, 3, 4] and out["rt_qual"] == list(range(5, 16))
+    assert (out["read_start"], out["read_end"], out["aln_start"], out["aln_end"], out["start_offset"], out["end_offset"]) == (1001, 1017, 1001, 1017, 0, 0)
+    fresh = {"read_seq": seq, "read_qual": list(range(16)), "cigar_string": "16M", "read_start": 1001, "splice_pattern": ("", "")}
+    miss = P.update_read_info_realn(fresh, aln, ref, 1001, 1005, "", False, lambda p, r, a: False)
+    assert miss["cigar_updated"] is False and "lt_cigar" not in miss
