@@ -157,3 +157,33 @@ def test_gpu_overhang_and_perfect_match_jobs(gpu, oracle_mod, port):
         a = _oracle_alignment(oracle_mod, port, r, contig, mat, len(r), len(r))
         assert ok == (contig[a.reference_start:a.reference_end] == r[a.read_start:a.read_end])
     assert got[0] is True and got[2] is True
+
+
+def test_gpu_update_reads_batch(gpu, oracle_mod, port):
+    """update_read_info's realignment branch for a whole grid_search response (pileup.pyx:847-911, varaln.pyx:1200-1216):
+    one GPU batch, then the CIGAR surgery; reads carrying the planted deletion come back with it in their BAM CIGAR."""
+    rng = np.random.default_rng(61)
+    genome, pos, indel_seq, reads, starts = _locus(rng, 80)
+    wins = [genome[st + 75 - 150:st + 75 + 150] for st in starts]
+    ref_starts = [st + 75 - 150 + 1 for st in starts]                        # 1-based genome position of window index 0
+    dicts = [{"read_seq": r, "read_qual": [30] * len(r), "cigar_string": "%dM" % len(r), "read_start": st + 1, "splice_pattern": ("", "")}
+             for r, st in zip(reads, starts)]
+    alt_genome = genome[:pos] + genome[pos + 6:]
+    # the caller's `Variant(...) == candidate` (normalised equality): same haplotype after applying (p, ref, alt)
+    same = lambda p, ref, alt: len(ref) == 7 and genome[:p - 1] + alt + genome[p - 1 + len(ref):] == alt_genome
+    # the candidate's normalised (left-aligned) position
+    cpos = pos
+    while genome[cpos - 1] == genome[cpos + 5]:
+        cpos -= 1
+    out = ip.update_reads_batch(dicts, wins, ref_starts, cpos, indel_seq, False, same, 3, 2, 3, 1)
+    mat = oracle_mod.dna_matrix(3, 2)
+    n_upd = 0
+    for d, r, w in zip(out, reads, wins):
+        a = _oracle_alignment(oracle_mod, port, r, w, mat, 3, 1)
+        if d["cigar_updated"]:
+            n_upd += 1
+            assert "6D" in d["cigar_string"] and "6D" in a.CIGAR and d["is_target"] and d["lt_flank"] + d["rt_flank"] in r
+            assert d["read_end"] - d["read_start"] + 1 == sum(int(t[:-1]) for t in d["cigar_list"] if t[-1] != "I")
+        else:
+            assert a.CIGAR is None or "6D" not in a.CIGAR or d["cigar_string"] == "%dM" % len(r)
+    assert n_upd > 15
