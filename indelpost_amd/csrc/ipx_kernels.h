@@ -782,8 +782,50 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                 }
                 vF &= ~fe;
             }
-            // step-by-step loop for the remaining reads, per-read exit
-            for (int k = 0; STEP && k < W; ++k) {
+            // The reference's loop for the remaining reads, with its data-dependent exit (ssw.c:302-313).
+            // 8-bit pass, up to 16 segments: one ROUND (all segments of one lane shift) at a time.  Inside a round step j
+            // touches only segment j, so every step's exit vote -- F_{j+1} > H'_j - gapO as signed bytes, H'_j = max(H_j, F_j) --
+            // depends on the round's incoming F alone: all votes are computed at once, each lane packs them into a bit per
+            // step, ONE lane-group OR per round (instead of one per step) tells for every step whether anybody voted, and the
+            // round is applied up to and including the first step nobody voted in.  (r02: the stepped form below cost ~20
+            // instructions and a wave-wide branch per step, ~22 steps per stepping column of config 2a.)
+            constexpr bool ROUNDS = STEP && BYTE && SMAX >= 1 && SMAX <= 16;
+            if (ROUNDS) {
+                const pk16 K = 0x00800080u, ONE = 0x00010001u;
+                for (int k = 0; k < W; ++k) {
+                    vF = xl_row_shr1(vF);
+                    if (!xl_any(vF != 0)) break;
+                    pk16 f = vF, acc = 0;
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) {
+                        if (j < S) {
+                            const pk16 hn = pk_max(H[j], f);
+                            f = pk_subus(f, ge);
+                            const pk16 d = pk_subus(f ^ K, pk_subus(hn, go) ^ K);     // != 0: this lane votes to go on after step j
+                            acc |= pk_minu(d, ONE) << j;                              // (j < 16: the halves stay apart)
+                        }
+                    }
+                    const pk16 V = group_or<W>(acc);                                  // bit j (per half): somebody voted at step j
+                    pk16 Mj = V ^ pk_add(V, ONE);                                     // bits 0..z, z = first step without a vote: the steps applied
+                    f = vF;
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) {
+                        if (j < S) {
+                            const pk16 h = pk_max(H[j], pk_mul(f, Mj & ONE));
+                            cmx = pk_max(cmx, h);
+                            H[j] = h;
+                            if (j == S - 1) Hlast = h;
+                            f = pk_subus(f, ge);
+                            Mj = pk_shr1(Mj);
+                        }
+                    }
+                    // a read goes on to the next round iff every step of this one had a vote; the others carry F = 0
+                    const pk16 full = pk_splat(S < 16 ? (1 << (S & 15)) - 1 : 0xFFFF);
+                    vF = f & ~pk_nzmask(~V & full);
+                }
+            }
+            // step-by-step form: the 16-bit pass (jobs with gap_open <= gap_ext) and 8-bit reads of more than 256 bp
+            for (int k = 0; STEP && !ROUNDS && k < W; ++k) {
                 vF = xl_row_shr1(vF);
                 if (W == 8 && l == 0) vF = 0;
                 if (!xl_any(vF != 0)) break;

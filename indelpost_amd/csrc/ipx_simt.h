@@ -74,6 +74,8 @@ IPX_DEV pk16 pk_minu(pk16 a, pk16 b) {
     unsigned l = pk_ulo(a) < pk_ulo(b) ? pk_ulo(a) : pk_ulo(b), h = pk_uhi(a) < pk_uhi(b) ? pk_uhi(a) : pk_uhi(b);
     return l | (h << 16);
 }
+IPX_DEV pk16 pk_mul(pk16 a, pk16 b) { return ((pk_ulo(a) * pk_ulo(b)) & 0xFFFFu) | (((pk_uhi(a) * pk_uhi(b)) & 0xFFFFu) << 16); }
+IPX_DEV pk16 pk_shr1(pk16 a) { return ((a >> 1) & 0x7FFF7FFFu); }
 IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return (v >> off) & ((1u << width) - 1u); }
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b)
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
@@ -159,6 +161,8 @@ IPX_DEV pk16 pk_subus(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_sub_
 IPX_DEV pk16 pk_max(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_max(IPX_S2(a), IPX_S2(b))); }            // v_pk_max_i16
 IPX_DEV pk16 pk_minu(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_min(IPX_U2(a), IPX_U2(b))); }           // v_pk_min_u16
 IPX_DEV pk16 pk_sext_hi8(pk16 x) { return IPX_PK(IPX_S2(x) >> 8); }   // per half: signed high byte -> 16 bit: v_pk_ashrrev_i16
+IPX_DEV pk16 pk_mul(pk16 a, pk16 b) { return IPX_PK(IPX_U2(a) * IPX_U2(b)); }                                     // v_pk_mul_lo_u16
+IPX_DEV pk16 pk_shr1(pk16 a) { return IPX_PK(IPX_U2(a) >> 1); }                                                    // v_pk_lshrrev_b16
 IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b): one v_perm_b32
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
