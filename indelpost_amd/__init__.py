@@ -18,31 +18,13 @@ from .batch import (GpuAligner, MultiStreamAligner, JobTable, BatchResult, IpxEr
 __version__ = "0.1.0"
 
 
-_WHY = ("%s (%s) is outside the hot path this package replaces (SURVEY.md section 8: pysam I/O, pileup and contig "
-        "construction, variant normalisation); use the reference implementation for it and plug this package in at "
+from .variant import Variant, NullVariant                                   # noqa: F401,E402
+from . import bamio                                                         # noqa: F401,E402
+from .pileup import make_pileup, dictize_read, fetch_reads, parse_spliced_read   # noqa: F401,E402
+
+_WHY = ("%s (%s) is outside the hot path this package replaces (SURVEY.md section 8: contig / consensus construction, "
+        "phasing, the orchestration state machine); use the reference implementation for it and plug this package in at "
         "make_aligner()/align() or, better, at the batched drivers align_pileup / find_targets_by_ssw / grid_align.")
-
-
-class NullVariant:
-    """indelpost/variant.pyx:9-60: what VariantAlignment returns when the target is not found; falsy, ref == alt == the
-    reference base at the locus.  Small enough to be kept whole (reference: a pysam.FastaFile duck type with fetch())."""
-
-    def __init__(self, chrom, pos, reference):
-        self.chrom = chrom
-        self.pos = pos
-        self.ref = reference.fetch(chrom, pos - 1, pos)
-        self.alt = self.ref
-        self.reference = reference
-
-    def __bool__(self):
-        return False
-
-
-class Variant:
-    """API shell with the reference's constructor signature (indelpost/variant.pyx:92)."""
-
-    def __init__(self, chrom, pos, ref, alt, reference, skip_validation=False):
-        raise NotImplementedError(_WHY % ("Variant", "indelpost/variant.pyx:62"))
 
 
 class VariantAlignment:

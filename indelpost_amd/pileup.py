@@ -173,3 +173,290 @@ def update_reads_batch(reads, ref_seqs, ref_starts, candidate_pos, candidate_ind
                       mismatch_penalty, device)[0]
     return [update_read_info_realn(r, a, w, s, candidate_pos, candidate_indel_seq, candidate_is_ins, is_candidate)
             for r, a, w, s in zip(reads, alns, ref_seqs, ref_starts)]
+
+
+# =====================================================================================================================
+# The pileup front-end: BAM reads around a target -> the read dicts everything above consumes.
+# Mirrors pileup.pyx:51-434 (make_pileup, fetch_reads, dictize_read, get_ref_seq, leftalign_indel_read, is_end_dirty,
+# leftalign_cigar, parse_spliced_read, is_within_intron) and the helpers of utilities.pyx they call (:187-330, :429-503).
+# `bam` / `reference` are pysam duck types (indelpost_amd.bamio provides pysam-free ones); `target` is a Variant.
+# Parity: the pure helpers are pinned by vectors from the reference's function bodies (oracle/gen_decoder_golden.py);
+# make_pileup / dictize_read as a whole have no executable reference here (no pysam): hand-derived cases only.
+# =====================================================================================================================
+import random
+
+_READ_ONLY = ("I", "S")
+_ALIGNED = ("M", "=", "X")
+
+
+def to_flat_list(lst_of_lst):
+    return [x for lst in lst_of_lst for x in lst]
+
+
+def count_lowqual_non_ref_bases(read_seq, ref_seq, quals, cigar_list, basequalthresh):
+    """mismatching aligned bases and inserted / clipped bases below the quality threshold (utilities.pyx:187-218)"""
+    i = j = cnt = 0
+    for tok in cigar_list:
+        op, n = tok[-1], int(tok[:-1])
+        if op in _ALIGNED:
+            for _ in range(n):
+                if read_seq[i] != ref_seq[j] and quals[i] < basequalthresh:
+                    cnt += 1
+                i += 1
+                j += 1
+        elif op in _READ_ONLY:
+            cnt += sum(1 for q in quals[i:i + n] if q < basequalthresh)
+            i += n
+        elif op == "D":
+            j += n
+    return cnt
+
+
+def get_mapped_subreads(cigarstring, aln_start_pos, aln_end_pos):
+    """genome intervals (inclusive) of the M/=/X runs (utilities.pyx:221-240)"""
+    res, pos = [], aln_start_pos
+    for tok in cigar_ptrn.findall(cigarstring):
+        op, n = tok[-1], int(tok[:-1])
+        if op in ("M", "X", "="):
+            res.append((pos, pos + n - 1))
+            pos += n
+        elif op not in ("I", "S", "H", "P"):
+            pos += n
+    return res
+
+
+def get_spliced_subreads(cigarstring, read_start_pos, read_end_pos):
+    """the exon pieces of a read, split at N (soft clips included in the outer pieces) (utilities.pyx:243-278)"""
+    if "N" not in cigarstring:
+        return [(read_start_pos, read_end_pos)]
+    pos, marks, prev = read_start_pos, [read_start_pos], "A"
+    for tok in cigar_ptrn.findall(cigarstring):
+        op, n = tok[-1], int(tok[:-1])
+        if op == "N":
+            marks.append(pos - 1)
+        elif prev == "N":
+            marks.append(pos)
+        if op not in ("I", "H", "P"):
+            pos += n
+        prev = op
+    if prev != "N":
+        marks.append(read_end_pos)
+    return [marks[i:i + 2] for i in range(0, len(marks), 2)]
+
+
+def get_end_pos(read_start_pos, lt_flank, cigarstring):
+    """genome position reached after consuming len(lt_flank) read bases (utilities.pyx:281-304)"""
+    pos, left, toks, i = read_start_pos - 1, len(lt_flank), cigar_ptrn.findall(cigarstring), 0
+    while left > 0:
+        op, n = toks[i][-1], int(toks[i][:-1])
+        if op in ("D", "N"):
+            pos += n
+        elif op == "I":
+            left -= n
+        elif op not in ("H", "P"):
+            left -= n
+            pos += n
+        i += 1
+    return pos + left
+
+
+def locate_indels(cigarstring, aln_start_pos):
+    """([(pos, len)] insertions, [(pos, len)] deletions): pos = genome position of the base left of the event
+    (utilities.pyx:307-328)"""
+    pos, ins, dels = aln_start_pos - 1, [], []
+    for tok in cigar_ptrn.findall(cigarstring):
+        op, n = tok[-1], int(tok[:-1])
+        if op == "I":
+            ins.append((pos, n))
+        elif op == "D":
+            dels.append((pos, n))
+            pos += n
+        elif op not in ("H", "P"):
+            pos += n
+    return ins, dels
+
+
+def split(data, cigarstring, target_pos, string_pos, is_for_ref, reverse):
+    """cut a read-side (or, is_for_ref, reference-side) sequence / quality array at genome position target_pos, walking
+    the CIGAR from string_pos (utilities.pyx:429-503).  Slices use the reference's index arithmetic unchanged, negative
+    indices included."""
+    moves = []
+    for tok in cigar_ptrn.findall(cigarstring):
+        op, n = tok[-1], int(tok[:-1])
+        if op == "N":
+            moves.append((0, n))
+        elif op == "I":
+            moves.append((0 if is_for_ref else n, 0))
+        elif op == "D":
+            moves.append((n if is_for_ref else 0, n))
+        elif op in ("H", "P"):
+            moves.append((0, 0))
+        else:
+            moves.append((n, n))
+    j = 0
+    if reverse:
+        string_pos += 1
+        data = data[::-1]
+        for d, g in moves[::-1]:
+            if not target_pos < string_pos:
+                break
+            string_pos -= g
+            j += d
+        k = j + string_pos - (target_pos + 1)
+        return data[k:][::-1], data[:k][::-1]
+    string_pos -= 1
+    for d, g in moves:
+        if not string_pos < target_pos:
+            break
+        string_pos += g
+        j += d
+    k = j + target_pos - string_pos
+    return data[:k], data[k:]
+
+
+def get_ref_seq(chrom, aln_start, aln_end, cigar_string, cigar_list, reference, unspl_loc_ref):
+    """the reference bases under the read's M and D runs (introns skipped) (pileup.pyx:269-298)"""
+    pos = aln_start - 1
+    if "N" not in cigar_string:
+        return unspl_loc_ref.get_ref_seq(pos, aln_end)
+    out = ""
+    for tok in cigar_list:
+        op, n = tok[-1], int(tok[:-1])
+        if op in ("M", "D"):
+            out += reference.fetch(chrom, pos, pos + n)
+            pos += n
+        elif op not in ("I", "S", "H", "P"):
+            pos += n
+    return out
+
+
+def leftalign_indel_read(chrom, pos, indel_len, indel_type, cigar_string, read_start, aln_start, read_seq, ref_seq, read_qual,
+                         reference):
+    """one indel of a read's own CIGAR as (pos, lt_flank, indel_seq, rt_flank, lt_ref, rt_ref, lt_qual, rt_qual, Variant)
+    (pileup.pyx:301-335)"""
+    from .variant import Variant
+    lt_flank, rt_flank = split(read_seq, cigar_string, pos, read_start, is_for_ref=False, reverse=False)
+    lt_ref, rt_ref = split(ref_seq, cigar_string, pos, aln_start, is_for_ref=True, reverse=False)
+    lt_qual, rt_qual = split(read_qual, cigar_string, pos, read_start, is_for_ref=False, reverse=False)
+    pad = reference.fetch(chrom, pos - 1, pos) if ("N" in cigar_string or not lt_ref) else lt_ref[-1]
+    if indel_type == "I":
+        indel_seq = rt_flank[:indel_len]
+        rt_flank, rt_qual = rt_flank[indel_len:], rt_qual[indel_len:]
+        var = Variant(chrom, pos, pad, pad + indel_seq, reference, skip_validation=True)
+    else:
+        indel_seq = rt_ref[:indel_len]
+        rt_ref = rt_ref[indel_len:]
+        var = Variant(chrom, pos, pad + indel_seq, pad, reference, skip_validation=True)
+    return pos, lt_flank, indel_seq, rt_flank, lt_ref, rt_ref, lt_qual, rt_qual, var
+
+
+def is_end_dirty(read_qual, basequalthresh, pos, read_start, read_end, cigar_string):
+    """low base quality among the three bases of the read end nearer to the target (pileup.pyx:338-356)"""
+    to_left, to_right = pos - read_start, read_end - pos
+    lefty = True if to_left < 0 else False if to_right < 0 else to_left <= to_right
+    if cigar_string.count("N") > 1:
+        return False
+    return min(read_qual[:3] if lefty else read_qual[-3:]) < basequalthresh
+
+
+def leftalign_cigar(cigarstring, target, read_start):
+    """move the target's gap in a read's CIGAR to its normalised position (pileup.pyx:359-377)"""
+    target.normalize(inplace=True)
+    lt, rt = split_cigar(cigarstring, target.pos, read_start)
+    if len(rt) < 3 or "M" not in rt[0] or "M" not in rt[2]:
+        return cigarstring
+    return "".join(lt) + rt[1] + str(int(rt[0][:-1]) + int(rt[2][:-1])) + "M" + "".join(rt[3:])
+
+
+def parse_spliced_read(cigar_string, read_start, read_end, pos, rpos):
+    """(is_covering, covering_subread, is_spliced, splice_pattern, intron_pattern) of a read relative to the target at
+    pos (right-most equivalent position rpos) (pileup.pyx:380-432)"""
+    pieces = get_spliced_subreads(cigar_string, read_start, read_end)
+    covering, sub = False, None
+    for p in pieces:
+        if p[0] <= pos <= p[1]:
+            covering, sub = True, tuple(p)
+        elif p[0] <= rpos <= p[1]:
+            covering, sub = True, tuple(p)
+            pos = rpos
+    if len(pieces) <= 1:
+        return covering, sub, False, ("", ""), (0, 0)
+    bounds = to_flat_list(pieces)[1:-1]
+    lt, rt, intron = [], [], (0, 0)
+    for i in range(0, len(bounds), 2):
+        a, b = bounds[i] + 1, bounds[i + 1] - 1
+        if b < pos:
+            lt.append("%d-%d" % (a, b))
+        elif pos < a - 1:
+            rt.append("%d-%d" % (a, b))
+        if a - 4 <= pos <= b:                       # overhang reads
+            intron = (a, b)
+    return covering, sub, True, (":".join(lt), ":".join(rt)), intron
+
+
+def is_within_intron(read, pos, window):
+    a, b = read["intron_pattern"]
+    return (a, b) != (0, 0) and a < pos - window and pos + window < b
+
+
+def fetch_reads(chrom, pos, bam, ref_len, window, exclude_duplicates):
+    """pileup.pyx:126-153 (including its quirk: with exclude_duplicates a read starting at reference position 0 is dropped)"""
+    pos -= 1
+    segs = bam.fetch(chrom, max(0, pos - window), min(pos + 1 + window, ref_len), until_eof=True)
+    if exclude_duplicates:
+        return [s for s in segs if not s.is_duplicate and not s.is_secondary and s.cigarstring and s.reference_start]
+    return [s for s in segs if not s.is_secondary and s.cigarstring]
+
+
+def dictize_read(read, chrom, pos, rpos, reference, unspl_loc_ref, basequalthresh):
+    """one BAM segment as the dict the rest of indelPost works on (pileup.pyx:156-266)"""
+    cigar_string = read.cigarstring
+    cigar_list = cigar_ptrn.findall(cigar_string)
+    aln_start = read.reference_start + 1
+    start_offset = int(cigar_list[0][:-1]) if cigar_list[0].endswith("S") else 0
+    read_start = aln_start - start_offset
+    aln_end = read.reference_end                       # (0-based exclusive = 1-based inclusive: not incremented)
+    if aln_end is None:
+        aln_end = aln_start + sum(int(c[:-1]) for c in cigar_list if c[-1] in ("M", "N", "D", "=", "X"))
+    end_offset = int(cigar_list[-1][:-1]) if cigar_list[-1].endswith("S") else 0
+    read_end = aln_end + end_offset
+    read_seq, read_qual = read.query_sequence, read.query_qualities
+    ref_seq = get_ref_seq(chrom, aln_start, aln_end, cigar_string, cigar_list, reference, unspl_loc_ref)
+    d = {"read": read, "read_seq": read_seq, "read_qual": read_qual, "ref_seq": ref_seq, "is_reverse": read.is_reverse,
+         "read_name": read.query_name, "mapq": read.mapping_quality, "start_offset": start_offset, "aln_start": aln_start,
+         "read_start": read_start, "end_offset": end_offset, "aln_end": aln_end, "read_end": read_end,
+         "cigar_string": cigar_string, "cigar_list": cigar_list, "is_reference_seq": read_seq == ref_seq, "I": [], "D": []}
+    d["low_qual_base_num"] = count_lowqual_non_ref_bases(read_seq, ref_seq, read_qual, cigar_list, basequalthresh)
+    d["is_end_dirty"] = is_end_dirty(read_qual, basequalthresh, pos, read_start, read_end, cigar_string)
+    d["is_dirty"] = sum(q <= basequalthresh for q in read_qual) / len(read_seq) > 0.15
+    insertions, deletions = locate_indels(cigar_string, read_start)
+    for key, events in (("I", insertions), ("D", deletions)):
+        for ev_pos, ev_len in events:
+            d[key].append(leftalign_indel_read(chrom, ev_pos, ev_len, key, cigar_string, read_start, aln_start, read_seq, ref_seq,
+                                               read_qual, reference))
+    (d["is_covering"], d["covering_subread"], d["is_spliced"], d["splice_pattern"], d["intron_pattern"]) = parse_spliced_read(
+        cigar_string, read_start, read_end, pos, rpos)
+    return d
+
+
+def make_pileup(target, bam, unspl_loc_ref, exclude_duplicates, window, downsamplethresh, basequalthresh):
+    """(pileup, sample_factor): the reads within `window` of the target as dicts, downsampled like the reference does
+    (random.seed(123), at most downsamplethresh deep, never below half of it) (pileup.pyx:51-111)"""
+    chrom, pos, reference = target.chrom, target.pos, target.reference
+    rpos = max(v.pos for v in target.generate_equivalents())
+    ref_len = reference.get_reference_length(chrom)
+    if chrom in bam.references:
+        bam_chrom = chrom
+    else:
+        bam_chrom = chrom.replace("chr", "") if chrom.startswith("chr") else "chr" + chrom
+    segs = fetch_reads(bam_chrom, pos, bam, ref_len, window, exclude_duplicates)
+    depth = bam.count(bam_chrom, pos - 1, pos, read_callback="all" if exclude_duplicates else "nofilter")
+    n_reads, sample_factor = len(segs), 1.0
+    if depth > downsamplethresh:
+        random.seed(123)
+        n_sample = int(n_reads * (downsamplethresh / depth))
+        if n_sample >= downsamplethresh / 2 > 0:
+            segs = random.sample(segs, n_sample)
+            sample_factor = n_reads / len(segs)
+    pileup = [dictize_read(s, chrom, pos, rpos, reference, unspl_loc_ref, basequalthresh) for s in segs]
+    return [r for r in pileup if not is_within_intron(r, pos, window)], sample_factor

@@ -131,8 +131,6 @@ def test_out_of_scope_shells_say_so():
     assert list(va)[1:4] == ["target", "bam", "window"] and va["window"].default == 50 and va["match_score"].default == 3 and \
         va["gap_open_penalty"].default == 3 and va["gap_extension_penalty"].default == 1 and va["downsample_threshold"].default == 1000
     with pytest.raises(NotImplementedError):
-        ip.Variant("1", 100, "A", "AT", None)
-    with pytest.raises(NotImplementedError):
         ip.VariantAlignment(None, None)
     with pytest.raises(NotImplementedError):
         ip.Contig(None, [], None, 20, 1)
