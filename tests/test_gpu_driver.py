@@ -187,3 +187,39 @@ def test_gpu_update_reads_batch(gpu, oracle_mod, port):
         else:
             assert a.CIGAR is None or "6D" not in a.CIGAR or d["cigar_string"] == "%dM" % len(r)
     assert n_upd > 15
+
+
+def test_gpu_bam_locus_to_target_reads(gpu, oracle_mod, port, tmp_path):
+    """BASELINE configs[2] in miniature, files first: a BAM and a FASTA on disk -> make_pileup (pileup.pyx:51-110) with the
+    pysam-free reader -> the reads without the target in their CIGAR are realigned in one GPU batch (localn.pyx:15-68).
+    Half the carriers are written to the BAM with the deletion soft-clipped away, as a mapper would leave them: the
+    realignment must find them again."""
+    from tests.test_variant_pileup import _locus as bam_locus
+    from indelpost_amd import bamio
+    from indelpost_amd.variant import Variant
+    genome, pos, segs, bam_path, fa_path = bam_locus(tmp_path, n_reads=90)
+    hidden = set()
+    for i, s in enumerate(segs):                         # hide the deletion of every other carrier behind a soft clip
+        if "6D" in s.cigarstring and "S" not in s.cigarstring and i % 2:
+            lt = s.cigartuples[0][1]
+            if lt >= 30:
+                s.cigartuples = [(0, lt), (4, 150 - lt)]
+                hidden.add(s.query_name)
+    bamio.write_bam(bam_path, [("chr1", len(genome))], segs)
+    assert len(hidden) > 5
+    fa, bam = bamio.FastaFile(fa_path), bamio.AlignmentFile(bam_path)
+    target = Variant("chr1", pos, genome[pos - 1:pos + 6], genome[pos - 1], fa)
+    u = ip.UnsplicedLocalReference("chr1", target.pos, len(genome), 50, fa)
+    pile, _ = ip.make_pileup(target, bam, u, True, 50, 1000, 20)
+    by_cigar = np.array([any(d[8] == target for d in r["D"]) for r in pile])
+    mask = ~by_cigar
+    lt, rt, ref_ref = genome[pos - 150:pos], genome[pos + 6:pos + 156], genome[pos - 150:pos + 156]
+    reads = [r["read_seq"] for r in pile]
+    is_t, und, pairs = ip.find_targets_by_ssw(reads, mask, target.indel_seq, target.count_repeats(), lt, "", rt, ref_ref, 3, 2, 3, 1)
+    mat = oracle_mod.dna_matrix(3, 2)
+    for k, r in enumerate(reads):
+        if mask[k]:
+            assert pairs[k] == (_oracle_alignment(oracle_mod, port, r, ref_ref, mat, 3, 1),
+                                _oracle_alignment(oracle_mod, port, r, lt + rt, mat, len(r), 1)), k
+    found = {pile[k]["read_name"] for k in np.flatnonzero(is_t)}
+    assert found == {n for n in hidden if n in {r["read_name"] for r in pile}} and not und.any()
