@@ -356,6 +356,17 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass, int na)
 //          bytes in the high byte of each half and one packed arithmetic shift sign-extends them.
 //          Read letter N and padding rows select the constant 0, so this needs mat[c][N] == 0 for every
 //          c (true for indelPost's matrix, sswpy.pyx:306-336).  No LDS traffic in the column loop.
+//   F16  = (16-bit passes, PERM, exact segLen) the same recurrence in packed HALF PRECISION.  A packed 16-bit VALU operation
+//          costs four cycles per wavefront whatever it computes (tools/ubench_issue.hip), so only the NUMBER of operations
+//          per cell counts, and gfx950's v_pk_maximum3_f16 takes three operands: H = max3(diag + score, E, F) is one
+//          operation instead of two, F = max3(F - gapE, H - gapO, 0) carries the floor the integer form gets from its
+//          saturating subtraction, two segments' H enter the column maximum at once, and v_perm_b32 delivers the score
+//          AS a half (high byte from the table, low byte 0) so the sign-extending shift goes too: 8.5 operations per
+//          segment instead of 11.  Integers up to 2048 and their sums are exact in half precision, so the results are
+//          bit-identical as long as no score can exceed 2047 (host: IpxBatch::f16_max_len, and every matrix entry a half
+//          with a zero low byte: 0..8, 10, 12, ...; device-guarded).  E is left without its floor at 0: max(E, 0) equals
+//          the reference's E by induction, and F >= 0 keeps H >= 0.  Non-negative halves order like integers, so the
+//          bookkeeping around the stripe (column maxima, best score, saved column) works on the bit patterns unchanged.
 // With the profile out of LDS the register file alone sets the occupancy.  The request below only nudges
 // the kernels that sit just above a waves-per-SIMD step (the reverse pass at segLen 17-19: 182 -> 170
 // VGPRs, 2 -> 3 waves).  Pushing harder (4 waves at segLen 19) was measured: +2 % speed for register
@@ -366,11 +377,12 @@ IPX_HD constexpr int ipx_dp_perm_waves(int smax)
     const int w = 512 / (4 * smax + 90);
     return w < 1 ? 1 : w;
 }
-template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false>
+template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false, bool F16 = false>
 IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow)
 {
     constexpr bool LOW = STAGE == IPX_STAGE_LOW, HIGH = STAGE == IPX_STAGE_HIGH;
     static_assert(STAGE == IPX_STAGE_EXACT || (W == 16 && !REV), "the bracket stages exist for the 8-bit forward pass");
+    static_assert(!F16 || (W == 8 && PERM && EXACT && STAGE == IPX_STAGE_EXACT), "the half-precision form exists for the exact-segLen selector-profile 16-bit passes");
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
     constexpr int NA = 2 * G;
@@ -393,7 +405,10 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
     uint32_t *maxcol = mc_lds ? (uint32_t *)(lds + 128) : b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);
 
     if (lane < 25) matl[lane] = b.mat[lane];
-    if (PERM && lane < 20) ((int8_t *)lds)[lane] = b.mat[(lane >> 2) * 5 + (lane & 3)];
+    if (PERM && lane < 20) {
+        const int v = b.mat[(lane >> 2) * 5 + (lane & 3)];
+        ((int8_t *)lds)[lane] = F16 ? (int8_t)(ipx_f16_from_int(v) >> 8) : (int8_t)v;          // F16: the score as a half, high byte
+    }
     IPX_SYNC();
 
     // Block b takes the b-th, (b + gridDim)-th, ... tile of the classes this launch OWNS.  An exact-segLen launch owns its one
@@ -463,8 +478,10 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                 }
             }
         }
-        const pk16 go = pk_make(gO[0], gO[1]), ge = pk_make(gE[0], gE[1]);
-        const pk16 term = pk_make(score1[0], score1[1]);
+        // F16: -gapO and -gapE as halves (the stripe adds them), the score to stop at as a half
+        const pk16 go = F16 ? pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1])) : pk_make(gO[0], gO[1]);
+        const pk16 ge = F16 ? pk_make((int)ipx_f16_from_int(-gE[0]), (int)ipx_f16_from_int(-gE[1])) : pk_make(gE[0], gE[1]);
+        const pk16 term = F16 ? pk_make((int)ipx_f16_from_uint((uint32_t)score1[0]), (int)ipx_f16_from_uint((uint32_t)score1[1])) : pk_make(score1[0], score1[1]);
         const pk16 capm1 = pk_splat(255 - b.bias - 1);          // overflow when colmax >= 255-bias (ssw.c:327)
         // closed-form lazy-F (below) applies to a read when gap_open > gap_ext
 #ifdef IPX_DEBUG_NOFAST
@@ -473,7 +490,8 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
         const pk16 fast_static = (gO[0] > gE[0] ? 0x0000FFFFu : 0u) | (gO[1] > gE[1] ? 0xFFFF0000u : 0u);
 #endif
         if (!STEP) {                                            // this variant has no step loop: refuse what would need it
-            const bool bad = (job[0] >= 0 && gO[0] <= gE[0]) || (job[1] >= 0 && gO[1] <= gE[1]);
+            bool bad = (job[0] >= 0 && gO[0] <= gE[0]) || (job[1] >= 0 && gO[1] <= gE[1]);
+            if (F16) bad = bad || L[0] > b.f16_max_len || L[1] > b.f16_max_len;     // ... or could leave the exact range of a half
             if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
         }
         const pk16 bigthr = pk_make(127 + gE[0], 127 + gE[1]);  // F carry > 127+gapE: signed-byte compare territory
@@ -482,7 +500,11 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
             int d[2][4];
             IPX_UNROLL
             for (int h = 0; h < 2; ++h)
-                for (int q = 0; q < 4; ++q) { int v = (S * gE[h]) << q; d[h][q] = v > 65535 ? 65535 : v; }
+                for (int q = 0; q < 4; ++q) {
+                    int v = (S * gE[h]) << q;
+                    d[h][q] = v > 65535 ? 65535 : v;
+                    if (F16) d[h][q] = (int)ipx_f16_from_int(-(v > 2047 ? 2047 : v));      // (a carry is <= 2047: minus 2047 ends it)
+                }
             D1 = pk_make(d[0][0], d[1][0]); D2 = pk_make(d[0][1], d[1][1]);
             D4 = pk_make(d[0][2], d[1][2]); D8 = pk_make(d[0][3], d[1][3]);
         }
@@ -634,7 +656,95 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     vF = pk_max(vF, tt);                                                                     \
                 }                                                                                            \
             }
-            if (!PERM) {
+            if (F16 && !IPX_STRIPE_ASM) {
+                // half-precision form, plain (emulator): go / ge hold -gapO / -gapE
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j) {
+                    const pk16 h = pkh_max3(pkh_add(vH, pk_perm(tab1, tab0, SEL[PERM ? j : 0])), E[j], vF);
+                    cmx = pkh_max(cmx, h);
+                    vH = H[j];
+                    H[j] = h;
+                    const pk16 tt = pkh_add(h, go);
+                    E[j] = pkh_max(pkh_add(E[j], ge), tt);                     // (no floor: see F16 above)
+                    vF = pkh_max3(pkh_add(vF, ge), tt, 0u);
+                }
+                Hlast = H[SA - 1];
+            } else if (F16) {
+#if IPX_STRIPE_ASM
+                // half-precision form, hand-scheduled like the integer stripe below: every operand is at least two
+                // instructions away from the packed operation that produced it, H is updated in place.
+                //   qj = diag + score of the segment about to be finished, em = its E - gapE   (prepared one block ahead)
+                //   p1 = score of the next segment                                             (prepared one block ahead)
+                if (SMAX > 0) {
+                    pk16 qj, em, p1 = 0, q2, emn, vFm, tt;
+                    qj = pkh_add(vH, pk_perm(tab1, tab0, SEL[0]));
+                    em = pkh_add(E[0], ge);
+                    if (SMAX > 1) p1 = pk_perm(tab1, tab0, SEL[SMAX > 1 ? 1 : 0]);
+                    asm volatile("s_nop 0");       // (the compiler does not see the packed reads inside the blocks: keep its last write a state away)
+                    // operands: 0 H[j], 1 E[j], 2 F, 3 p1, 4 column maximum | 5 q2, 6 em', 7 F', 8 tt (temporaries / next block's inputs) |
+                    //           9 qj, 10 em, 11 E[j+1], 12 selector of segment j+2, 13/14 score tables, 15 -gapO, 16 -gapE, 17 H[j-1]
+#define IPX_H_OPS                                                                                                              \
+                        : "+v"(H[j]), "+v"(E[j]), "+v"(vF), "+v"(p1), "+v"(cmx), "=&v"(q2), "=&v"(emn), "=&v"(vFm), "=&v"(tt)          \
+                        : "v"(qj), "v"(em), "v"(E[j + 1 < SMAX ? j + 1 : 0]), "v"(SEL[j + 2 < SMAX ? j + 2 : 0]), "v"(tab0), "v"(tab1),  \
+                          "v"(go), "v"(ge), "v"(H[j > 0 ? j - 1 : 0])
+#define IPX_H_CMX3 "v_pk_maximum3_f16 %4, %4, %17, %0\n\t"     /* column maximum: two segments at once (odd j) */
+#define IPX_H_HEAD                                                                                      \
+                        "v_pk_add_f16 %5, %0, %3\n\t"               /* q2 = H[j](old) + score[j+1]          */ \
+                        "v_pk_add_f16 %7, %2, %16\n\t"              /* F' = F - gapE                        */ \
+                        "v_pk_maximum3_f16 %0, %9, %1, %2\n\t"      /* H[j] = max3(qj, E[j], F)             */
+#define IPX_H_TAIL                                                                                      \
+                        "v_pk_maximum3_f16 %2, %7, %8, 0\n\t"       /* F = max3(F', tt, 0)                  */ \
+                        "v_pk_max_f16 %1, %10, %8"                   /* E[j] = max(em, tt)                   */
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) {
+                        if (j + 2 < SMAX) {
+                            if (j & 1)
+                                asm volatile(IPX_H_HEAD
+                                             "v_perm_b32 %3, %14, %13, %12\n\t"          /* score[j+2], already a half */
+                                             "v_pk_add_f16 %8, %0, %15\n\t"              /* tt = H[j] - gapO           */
+                                             "v_pk_add_f16 %6, %11, %16\n\t"             /* em' = E[j+1] - gapE        */
+                                             IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
+                            else
+                                asm volatile(IPX_H_HEAD
+                                             "v_perm_b32 %3, %14, %13, %12\n\t"
+                                             "v_pk_add_f16 %8, %0, %15\n\t"
+                                             "v_pk_add_f16 %6, %11, %16\n\t"
+                                             IPX_H_TAIL IPX_H_OPS);
+                        } else if (j + 1 < SMAX) {
+                            if (j & 1)
+                                asm volatile(IPX_H_HEAD
+                                             "v_pk_add_f16 %6, %11, %16\n\t"
+                                             "v_pk_add_f16 %8, %0, %15\n\t"
+                                             IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
+                            else
+                                asm volatile(IPX_H_HEAD
+                                             "v_pk_add_f16 %6, %11, %16\n\t"
+                                             "v_pk_add_f16 %8, %0, %15\n\t"
+                                             "s_nop 0\n\t"
+                                             IPX_H_TAIL IPX_H_OPS);
+                        } else {
+                            if (j & 1)
+                                asm volatile("v_pk_maximum3_f16 %0, %9, %1, %2\n\t"
+                                             "v_pk_add_f16 %7, %2, %16\n\t"
+                                             "v_pk_add_f16 %8, %0, %15\n\t"
+                                             IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
+                            else
+                                asm volatile("v_pk_maximum3_f16 %0, %9, %1, %2\n\t"
+                                             "v_pk_add_f16 %7, %2, %16\n\t"
+                                             "v_pk_add_f16 %8, %0, %15\n\t"
+                                             "v_pk_max_f16 %4, %4, %0\n\t"
+                                             IPX_H_TAIL IPX_H_OPS);
+                        }
+                        qj = q2; em = emn;
+                    }
+                    Hlast = H[SA - 1];
+#undef IPX_H_OPS
+#undef IPX_H_CMX3
+#undef IPX_H_HEAD
+#undef IPX_H_TAIL
+                }
+#endif
+            } else if (!PERM) {
                 IPX_DP_STRIPE(pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]))
             } else if (!IPX_STRIPE_ASM || !EXACT) {
                 IPX_DP_STRIPE(pk_sext_hi8(pk_perm(tab1, tab0, SEL[PERM ? j : 0])))
@@ -731,13 +841,56 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                 if (W == 8 && l == 0) x = 0;
                 {   // (unconditional: a carry-free column is rare, and a branch here costs a copy of every H register)
                     pk16 y;
+                    if (F16) {                                  // (D1.. hold the negated decays as halves)
+                        y = xl_row_shr<1>(x); if (l < 1) y = 0; x = pkh_max(x, pkh_add(y, D1));
+                        y = xl_row_shr<2>(x); if (l < 2) y = 0; x = pkh_max(x, pkh_add(y, D2));
+                        y = xl_row_shr<4>(x); if (l < 4) y = 0; x = pkh_max(x, pkh_add(y, D4));
+                    } else {
                     y = xl_row_shr<1>(x); if (W == 8 && l < 1) y = 0; x = pk_max(x, pk_subus(y, D1));
                     y = xl_row_shr<2>(x); if (W == 8 && l < 2) y = 0; x = pk_max(x, pk_subus(y, D2));
                     y = xl_row_shr<4>(x); if (W == 8 && l < 4) y = 0; x = pk_max(x, pk_subus(y, D4));
                     if (W == 16) { y = xl_row_shr<8>(x); x = pk_max(x, pk_subus(y, D8)); }
-                    cmx = pk_max(cmx, x);
+                    }
+                    cmx = pk_max(cmx, x);                       // (both non-negative: halves order like integers)
                     pk16 a = x;
-                    if (PERM && EXACT && IPX_STRIPE_ASM) {
+                    if (F16 && IPX_STRIPE_ASM) {
+#if IPX_STRIPE_ASM
+                        // the integer apply below with the half-precision operations (ge = -gapE)
+                        pk16 a2;
+                        IPX_UNROLL
+                        for (int j = 0; j < SMAX; j += 4) {
+                            if (j + 3 < SMAX)
+                                asm volatile("v_pk_add_f16 %5, %4, %6\n\tv_pk_max_f16 %0, %0, %4\n\t"
+                                             "v_pk_add_f16 %4, %5, %6\n\tv_pk_max_f16 %1, %1, %5\n\t"
+                                             "v_pk_add_f16 %5, %4, %6\n\tv_pk_max_f16 %2, %2, %4\n\t"
+                                             "v_pk_add_f16 %4, %5, %6\n\tv_pk_max_f16 %3, %3, %5"
+                                             : "+v"(H[j]), "+v"(H[j + 1 < SMAX ? j + 1 : 0]), "+v"(H[j + 2 < SMAX ? j + 2 : 0]),
+                                               "+v"(H[j + 3 < SMAX ? j + 3 : 0]), "+v"(a), "=&v"(a2)
+                                             : "v"(ge));
+                            else if (j + 2 < SMAX)
+                                asm volatile("v_pk_add_f16 %4, %3, %5\n\tv_pk_max_f16 %0, %0, %3\n\t"
+                                             "v_pk_add_f16 %3, %4, %5\n\tv_pk_max_f16 %1, %1, %4\n\t"
+                                             "s_nop 0\n\tv_pk_max_f16 %2, %2, %3"
+                                             : "+v"(H[j]), "+v"(H[j + 1 < SMAX ? j + 1 : 0]), "+v"(H[j + 2 < SMAX ? j + 2 : 0]), "+v"(a), "=&v"(a2)
+                                             : "v"(ge));
+                            else if (j + 1 < SMAX)
+                                asm volatile("v_pk_add_f16 %3, %2, %4\n\tv_pk_max_f16 %0, %0, %2\n\t"
+                                             "s_nop 0\n\tv_pk_max_f16 %1, %1, %3"
+                                             : "+v"(H[j]), "+v"(H[j + 1 < SMAX ? j + 1 : 0]), "+v"(a), "=&v"(a2)
+                                             : "v"(ge));
+                            else if (j < SMAX)
+                                asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(H[j]) : "v"(a));
+                        }
+                        Hlast = H[SA - 1];
+#endif
+                    } else if (F16) {
+                        IPX_UNROLL
+                        for (int j = 0; j < SMAX; ++j) {
+                            H[j] = pkh_max(H[j], a);
+                            a = pkh_add(a, ge);
+                        }
+                        Hlast = H[SA - 1];
+                    } else if (PERM && EXACT && IPX_STRIPE_ASM) {
 #if IPX_STRIPE_ASM
                         // H[j] = max(H[j], a), a -= gapE, hand-scheduled like the stripe: two alternating carry
                         // registers keep every operand two instructions away from the op that produced it,
@@ -940,7 +1093,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     IpxResult r = b.res[job[h]];
                     // a 16-bit result may already sit in the record (IPX_PASS_WORD_FIRST): an overflowing 8-bit pass keeps it
                     const bool has_word = r.mode == IPX_MODE_NEED_BYTE_CHECK || r.mode == IPX_MODE_NEED_BYTE_EXACT_W;
-                    const int s2 = maskLen >= 15 ? (int)(key2 >> 16) : 0;                                       // ssw.c:864-870
+                    const int s2 = maskLen >= 15 ? (int)(F16 ? ipx_f16_to_uint(key2 >> 16) : (key2 >> 16)) : 0;  // ssw.c:864-870
                     const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
                     if (HIGH) {
                         // the record holds the lower-bound stage's outputs: equal outputs certify them (see STAGE above);
@@ -961,7 +1114,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     } else {
                         r.mode = lost ? IPX_MODE_NEED_BYTE_HIGH                                                // lower-bound outputs kept for the upper-bound stage
                                       : BYTE ? IPX_MODE_BYTE : (pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD);
-                        r.score1 = (uint16_t)bh;
+                        r.score1 = (uint16_t)(F16 ? ipx_f16_to_uint(bh) : bh);
                         r.ref_end1 = eref;
                         r.read_end1 = end_read;
                         r.read_begin1 = -1;
@@ -974,7 +1127,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
             } else {
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
-                    const unsigned best_rev = (BYTE && overflow) ? 255u : bh;
+                    const unsigned best_rev = (BYTE && overflow) ? 255u : (F16 ? ipx_f16_to_uint(bh) : bh);
                     r.ref_begin1 = eref;                                                                       // ssw.c:885
                     r.read_begin1 = rend1[h] - end_read;                                                       // ssw.c:886
                     if ((unsigned)score1[h] > best_rev) r.flag = 2;                                            // ssw.c:888-891
@@ -1652,7 +1805,13 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_DP_UNIT_G(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, true)
 #define IPX_DP_UNIT_H(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, false)                                                                 \
     X(8, 16, true, false, IPX_STAGE_EXACT, false) X(8, 32, true, false, IPX_STAGE_EXACT, false) X(8, IPX_MAX_SEG, true, false, IPX_STAGE_EXACT, false)
+// the half-precision form of the 16-bit selector-profile passes (k_dp_pass F16)
+#define IPX_DP_DEFINE_H(W, S, REV, EX, STAGE, PERM) template __global__ void k_dp_pass<W, S, REV, EX, STAGE, PERM, true> IPX_DP_SIG;
+#define IPX_DP_EXTERN_H(W, S, REV, EX, STAGE, PERM) extern template __global__ void k_dp_pass<W, S, REV, EX, STAGE, PERM, true> IPX_DP_SIG;
+#define IPX_DP_UNIT_I(X) IPX_DP_FAMILY(X, 8, false, IPX_STAGE_EXACT, true)
+#define IPX_DP_UNIT_J(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, true)
 #if defined(IPX_EXTERN_KERNELS)
+IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)
 #endif

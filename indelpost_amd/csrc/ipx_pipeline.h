@@ -93,8 +93,20 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
     // (k_dp_pass, STEP): jobs with gap_open <= gap_ext are a class of their own and take the LDS-profile kernels
     const bool perm = ipx_perm_profile_ok(b.mat, routing) && (!slow || (W == 16 && STAGE == IPX_STAGE_EXACT));
     constexpr int NP_STAGE = STAGE == IPX_STAGE_HIGH ? IPX_STAGE_EXACT : STAGE;   // (the upper-bound stage exists in selector-profile form only)
+    // 16-bit passes: the half-precision form where every score of the class stays exact in a half (IpxBatch::f16_max_len)
+    bool f16 = false;
+    if constexpr (W == 8 && STAGE == IPX_STAGE_EXACT) f16 = perm && !slow && !(routing & IPX_ROUTE_NO_F16) && 8 * S <= b.f16_max_len;
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
+        if constexpr (W == 8 && STAGE == IPX_STAGE_EXACT) {                                                  \
+            if (f16) {                                                                                       \
+                be.note_f16(N);                                                                              \
+                be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, STAGE, true, true>, be.dp_grid(pass, cls), 64, \
+                          ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, cls, maxcols,      \
+                          pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0), (uint64_t)0, (uint64_t)0);  \
+                break;                                                                                       \
+            }                                                                                                \
+        }                                                                                                    \
         if (perm)                                                                                            \
             be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, STAGE, true>, be.dp_grid(pass, cls), 64,     \
                       ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, cls, maxcols,          \
@@ -320,6 +332,19 @@ static inline int ipx_bracket_min_len(const int8_t *mat)
     for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
     if (mx <= 0) return 0x7FFFFFFF;
     return (160 + mx - 1) / mx;
+}
+
+// longest read that may take the half-precision form of the 16-bit passes (k_dp_pass F16): every matrix entry must be a half
+// with a zero low byte (v_perm_b32 delivers only the high byte) and no score may exceed 2047, the last integer before halves
+// step by 2.  0 = the form does not apply.
+static inline int ipx_f16_max_len(const int8_t *mat)
+{
+    int mx = 0;
+    for (int k = 0; k < 25; ++k) {
+        if (ipx_f16_from_int(mat[k]) & 0xFFu) return 0;
+        if (mat[k] > mx) mx = mat[k];
+    }
+    return mx > 0 ? 2047 / mx : 0;
 }
 
 // which classes can occur in which pass, for the current scoring parameters (host-known facts only)

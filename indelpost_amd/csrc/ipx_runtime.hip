@@ -147,6 +147,7 @@ struct HipBackend {
         return (int)(g < cap ? g : cap);
     }
     void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 256 + cls) * 32 + na; }
+    void note_f16(int) {}
     void copy_u32(uint32_t *dst, const uint32_t *src, int n)
     {
         hipError_t e = hipMemcpyAsync(dst, src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream);
@@ -429,6 +430,7 @@ int ipx_run(ipx_ctx *c)
     b.word_first_len = (c->routing & IPX_ROUTE_NO_WORD_FIRST) ? 0 : ipx_word_first_len(c->mat, c->bias);
     b.use_bracket = ipx_perm_profile_ok(c->mat, c->routing) && !(c->routing & IPX_ROUTE_NO_BRACKET);
     b.bracket_min_len = ipx_bracket_min_len(c->mat);
+    b.f16_max_len = ipx_f16_max_len(c->mat);
     b.byte_safe_len = ipx_byte_safe_len(c->mat, c->bias);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;

@@ -102,6 +102,43 @@ IPX_DEV uint32_t load_global_u32(const uint32_t *p) { return *p; }
 IPX_DEV void store_global_u32(uint32_t *p, uint32_t v) { *p = v; }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+// packed IEEE half precision (v_pk_add_f16 / v_pk_max_f16 / v_pk_maximum3_f16), round to nearest even; no NaN handling
+// (the kernels only ever hold finite values)
+IPX_DEV float emu_h2f(uint32_t h)
+{
+    const uint32_t s = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    float v;
+    if (e == 0) v = (float)m * (1.0f / 16777216.0f);                 // subnormal: m * 2^-24
+    else if (e == 31) v = 65536.0f * 65536.0f;                      // inf (never produced here)
+    else { v = (float)(0x400u | m); int k = (int)e - 25; while (k > 0) { v *= 2.0f; --k; } while (k < 0) { v *= 0.5f; ++k; } }
+    return s ? -v : v;
+}
+IPX_DEV uint32_t emu_f2h(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t s = (x >> 16) & 0x8000u;
+    const int e = (int)((x >> 23) & 0xFF) - 127 + 15;
+    uint32_t m = x & 0x7FFFFFu;
+    if (((x >> 23) & 0xFF) == 0) return s;                           // zero (float subnormals are far below half range)
+    if (e >= 31) return s | 0x7C00u;
+    if (e <= 0) {                                                    // half subnormal
+        if (e < -10) return s;
+        m |= 0x800000u;
+        const int sh = 14 - e;                                       // bits dropped
+        uint32_t r = m >> sh;
+        const uint32_t rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return s | r;
+    }
+    uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;          // (a carry into the exponent is the right answer)
+    return s | r;
+}
+IPX_DEV float emu_hmax(float a, float b) { return a > b ? a : b; }
+IPX_DEV pk16 pkh_add(pk16 a, pk16 b) { return emu_f2h(emu_h2f(a & 0xFFFFu) + emu_h2f(b & 0xFFFFu)) | (emu_f2h(emu_h2f(a >> 16) + emu_h2f(b >> 16)) << 16); }
+IPX_DEV pk16 pkh_max(pk16 a, pk16 b) { return emu_f2h(emu_hmax(emu_h2f(a & 0xFFFFu), emu_h2f(b & 0xFFFFu))) | (emu_f2h(emu_hmax(emu_h2f(a >> 16), emu_h2f(b >> 16))) << 16); }
+IPX_DEV pk16 pkh_max3(pk16 a, pk16 b, pk16 c) { return pkh_max(pkh_max(a, b), c); }
 
 #else
 // ------------------------------------------------------------------------------------------------
@@ -176,6 +213,12 @@ IPX_DEV uint32_t load_global_u32(const uint32_t *p) { return *(const __attribute
 IPX_DEV void store_global_u32(uint32_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t *)p = v; }
 IPX_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 IPX_DEV uint32_t atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+// packed half precision: v_pk_add_f16, v_pk_max_f16, v_pk_maximum3_f16 (new in gfx950)
+typedef _Float16 ipx_h2 __attribute__((ext_vector_type(2)));
+#define IPX_H2(x) __builtin_bit_cast(ipx_h2, (x))
+IPX_DEV pk16 pkh_add(pk16 a, pk16 b) { return IPX_PK(IPX_H2(a) + IPX_H2(b)); }
+IPX_DEV pk16 pkh_max(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_max(IPX_H2(a), IPX_H2(b))); }
+IPX_DEV pk16 pkh_max3(pk16 a, pk16 b, pk16 c) { return IPX_PK(__builtin_elementwise_maximum(__builtin_elementwise_maximum(IPX_H2(a), IPX_H2(b)), IPX_H2(c))); }
 #endif
 
 // ---- helpers shared by both builds -------------------------------------------------------------
@@ -188,3 +231,21 @@ IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { return (a & mask) | (b & ~ma
 IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { pk16 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b)); return r; }
 #endif
 IPX_DEV pk16 pk_splat(int v) { return pk_make(v, v); }
+// half-precision bit pattern of an integer 0..2047 (exact), and back (non-negative, integer valued)
+IPX_HD uint32_t ipx_f16_from_uint(uint32_t v)
+{
+    if (v == 0) return 0;
+    if (v > 2047u) v = 2047u;
+    int e = 10;
+    while (!((v >> e) & 1u)) --e;
+    return ((uint32_t)(e + 15) << 10) | ((v << (10 - e)) & 0x3FFu);
+}
+IPX_HD uint32_t ipx_f16_to_uint(uint32_t p)
+{
+    const int e = (int)((p >> 10) & 31u);
+    if (e < 15) return 0;
+    const uint32_t m = 0x400u | (p & 0x3FFu);
+    return e >= 25 ? m << (e - 25) : m >> (25 - e);
+}
+// signed small integer -> half pattern (sign bit + magnitude)
+IPX_HD uint32_t ipx_f16_from_int(int v) { return v < 0 ? (0x8000u | ipx_f16_from_uint((uint32_t)(-v))) : ipx_f16_from_uint((uint32_t)v); }

@@ -63,6 +63,7 @@ enum {
     IPX_ROUTE_NO_BRACKET = 4,      // no upper-bound stage: a read the lower-bound stage cannot settle goes to the stepped pass
     IPX_ROUTE_TB_NO_FUSE = 8,      // one traceback launch per band width even for small batches
     IPX_ROUTE_NO_MC_LDS = 16,      // column maxima in the global scratch even when they would fit in LDS
+    IPX_ROUTE_NO_F16 = 32,         // 16-bit passes in packed integer arithmetic even where the half-precision form applies
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels
@@ -92,6 +93,8 @@ struct IpxBatch {
     int32_t byte_safe_len;      // reads shorter than this cannot reach 255-bias (len * max(mat) < 255-bias): the lower-bound stage
                                 //   has nothing to offer them but the bracket; below bracket_min_len they start in the stepped
                                 //   pass directly; speed only
+    int32_t f16_max_len;        // reads up to this length may take the half-precision form of the 16-bit passes (k_dp_pass F16): every
+                                //   matrix entry is a half whose low byte is 0 and len * max(mat) <= 2047; 0 = never; speed only
     uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)

@@ -44,7 +44,7 @@ def load(d, counter):
 
 def bench_name(k):
     """rocprof kernel symbol -> kernel class name of bench.py (ipx_kernel_class_name)"""
-    m = re.match(r"void k_dp_pass<(\d+), (\d+), (true|false), (true|false), (\d+)(?:, (true|false))?>", k)
+    m = re.match(r"void k_dp_pass<(\d+), (\d+), (true|false), (true|false), (\d+)(?:, (?:true|false))*>", k)
     if m:
         w, s, rev, exact, stage = int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true", int(m.group(5))
         if w == 16:

@@ -171,6 +171,7 @@ struct EmuBackend {
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
     void copy_u32(uint32_t *dst, const uint32_t *src, int n) { memcpy(dst, src, sizeof(uint32_t) * (size_t)n); }
     void note_dp(int, int, int, int) {}
+    void note_f16(int S) { ++launches[IPX_KEY(IPX_K_INIT, 200 + S)]; }   // (test visibility: half-precision launches per segLen, under unused keys)
     template <class K, class... A>
     void launch(int kclass, K kern, int grid, int block, int lds, A... args)
     {
@@ -223,6 +224,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.word_first_len = (routing & IPX_ROUTE_NO_WORD_FIRST) ? 0 : ipx_word_first_len(mat, -bias);
     b.use_bracket = ipx_perm_profile_ok(mat, routing) && !(routing & IPX_ROUTE_NO_BRACKET);
     b.bracket_min_len = ipx_bracket_min_len(mat);
+    b.f16_max_len = ipx_f16_max_len(mat);
     b.byte_safe_len = ipx_byte_safe_len(mat, -bias);
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
