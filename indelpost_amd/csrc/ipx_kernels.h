@@ -327,6 +327,102 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass, int na)
 #define IPX_STRIPE_ASM 0
 #endif
 // ------------------------------------------------------------------------------------------------
+// One column of the striped recurrence in packed half precision (k_dp_pass F16, k_dp_skew): H, E updated in place, vF = F
+// entering segment 0 on entry and F leaving the last segment on exit, cmx = maximum of the new H with the cmx passed in.
+// go / ge hold -gapO / -gapE as halves, tab0 / tab1 the score tables of the two window letters, SEL the selectors.
+// ------------------------------------------------------------------------------------------------
+template <int SMAX>
+IPX_DEV void dp_stripe_f16(pk16 (&H)[SMAX > 0 ? SMAX : 1], pk16 (&E)[SMAX > 0 ? SMAX : 1], const pk16 (&SEL)[SMAX > 0 ? SMAX : 1],
+                           pk16 &vF, pk16 &cmx, pk16 vH, const uint32_t tab0, const uint32_t tab1, const pk16 go, const pk16 ge)
+{
+#if !IPX_STRIPE_ASM
+    // plain form (emulator)
+    IPX_UNROLL
+    for (int j = 0; j < SMAX; ++j) {
+        const pk16 h = pkh_max3(pkh_add(vH, pk_perm(tab1, tab0, SEL[j])), E[j], vF);
+        cmx = pkh_max(cmx, h);
+        vH = H[j];
+        H[j] = h;
+        const pk16 tt = pkh_add(h, go);
+        E[j] = pkh_max(pkh_add(E[j], ge), tt);                     // (no floor: see F16 at k_dp_pass)
+        vF = pkh_max3(pkh_add(vF, ge), tt, 0u);
+    }
+#else
+    // half-precision form, hand-scheduled like the integer stripe below: every operand is at least two
+    // instructions away from the packed operation that produced it, H is updated in place.
+    //   qj = diag + score of the segment about to be finished, em = its E - gapE   (prepared one block ahead)
+    //   p1 = score of the next segment                                             (prepared one block ahead)
+    if (SMAX > 0) {
+        pk16 qj, em, p1 = 0, q2, emn, vFm, tt;
+        qj = pkh_add(vH, pk_perm(tab1, tab0, SEL[0]));
+        em = pkh_add(E[0], ge);
+        if (SMAX > 1) p1 = pk_perm(tab1, tab0, SEL[SMAX > 1 ? 1 : 0]);
+        asm volatile("s_nop 0");       // (the compiler does not see the packed reads inside the blocks: keep its last write a state away)
+        // operands: 0 H[j], 1 E[j], 2 F, 3 p1, 4 column maximum | 5 q2, 6 em', 7 F', 8 tt (temporaries / next block's inputs) |
+        //           9 qj, 10 em, 11 E[j+1], 12 selector of segment j+2, 13/14 score tables, 15 -gapO, 16 -gapE, 17 H[j-1]
+#define IPX_H_OPS                                                                                                              \
+            : "+v"(H[j]), "+v"(E[j]), "+v"(vF), "+v"(p1), "+v"(cmx), "=&v"(q2), "=&v"(emn), "=&v"(vFm), "=&v"(tt)          \
+            : "v"(qj), "v"(em), "v"(E[j + 1 < SMAX ? j + 1 : 0]), "v"(SEL[j + 2 < SMAX ? j + 2 : 0]), "v"(tab0), "v"(tab1),  \
+              "v"(go), "v"(ge), "v"(H[j > 0 ? j - 1 : 0])
+#define IPX_H_CMX3 "v_pk_maximum3_f16 %4, %4, %17, %0\n\t"     /* column maximum: two segments at once (odd j) */
+#define IPX_H_HEAD                                                                                      \
+            "v_pk_add_f16 %5, %0, %3\n\t"               /* q2 = H[j](old) + score[j+1]          */ \
+            "v_pk_add_f16 %7, %2, %16\n\t"              /* F' = F - gapE                        */ \
+            "v_pk_maximum3_f16 %0, %9, %1, %2\n\t"      /* H[j] = max3(qj, E[j], F)             */
+#define IPX_H_TAIL                                                                                      \
+            "v_pk_maximum3_f16 %2, %7, %8, 0\n\t"       /* F = max3(F', tt, 0)                  */ \
+            "v_pk_max_f16 %1, %10, %8"                   /* E[j] = max(em, tt)                   */
+        IPX_UNROLL
+        for (int j = 0; j < SMAX; ++j) {
+            if (j + 2 < SMAX) {
+                if (j & 1)
+                    asm volatile(IPX_H_HEAD
+                                 "v_perm_b32 %3, %14, %13, %12\n\t"          /* score[j+2], already a half */
+                                 "v_pk_add_f16 %8, %0, %15\n\t"              /* tt = H[j] - gapO           */
+                                 "v_pk_add_f16 %6, %11, %16\n\t"             /* em' = E[j+1] - gapE        */
+                                 IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
+                else
+                    asm volatile(IPX_H_HEAD
+                                 "v_perm_b32 %3, %14, %13, %12\n\t"
+                                 "v_pk_add_f16 %8, %0, %15\n\t"
+                                 "v_pk_add_f16 %6, %11, %16\n\t"
+                                 IPX_H_TAIL IPX_H_OPS);
+            } else if (j + 1 < SMAX) {
+                if (j & 1)
+                    asm volatile(IPX_H_HEAD
+                                 "v_pk_add_f16 %6, %11, %16\n\t"
+                                 "v_pk_add_f16 %8, %0, %15\n\t"
+                                 IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
+                else
+                    asm volatile(IPX_H_HEAD
+                                 "v_pk_add_f16 %6, %11, %16\n\t"
+                                 "v_pk_add_f16 %8, %0, %15\n\t"
+                                 "s_nop 0\n\t"
+                                 IPX_H_TAIL IPX_H_OPS);
+            } else {
+                if (j & 1)
+                    asm volatile("v_pk_maximum3_f16 %0, %9, %1, %2\n\t"
+                                 "v_pk_add_f16 %7, %2, %16\n\t"
+                                 "v_pk_add_f16 %8, %0, %15\n\t"
+                                 IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
+                else
+                    asm volatile("v_pk_maximum3_f16 %0, %9, %1, %2\n\t"
+                                 "v_pk_add_f16 %7, %2, %16\n\t"
+                                 "v_pk_add_f16 %8, %0, %15\n\t"
+                                 "v_pk_max_f16 %4, %4, %0\n\t"
+                                 IPX_H_TAIL IPX_H_OPS);
+            }
+            qj = q2; em = emn;
+        }
+#undef IPX_H_OPS
+#undef IPX_H_CMX3
+#undef IPX_H_HEAD
+#undef IPX_H_TAIL
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_dp_pass: one striped Smith-Waterman pass over a tile of 128/W reads per wavefront
 //   W    = SSE lanes of the reference pass: 16 (8-bit semantics) or 8 (16-bit semantics)
 //   SMAX = segLen capacity held in registers.  EXACT: the tile's segLen S == SMAX is a compile-time
@@ -656,94 +752,9 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     vF = pk_max(vF, tt);                                                                     \
                 }                                                                                            \
             }
-            if (F16 && !IPX_STRIPE_ASM) {
-                // half-precision form, plain (emulator): go / ge hold -gapO / -gapE
-                IPX_UNROLL
-                for (int j = 0; j < SMAX; ++j) {
-                    const pk16 h = pkh_max3(pkh_add(vH, pk_perm(tab1, tab0, SEL[PERM ? j : 0])), E[j], vF);
-                    cmx = pkh_max(cmx, h);
-                    vH = H[j];
-                    H[j] = h;
-                    const pk16 tt = pkh_add(h, go);
-                    E[j] = pkh_max(pkh_add(E[j], ge), tt);                     // (no floor: see F16 above)
-                    vF = pkh_max3(pkh_add(vF, ge), tt, 0u);
-                }
+            if constexpr (F16) {
+                dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
                 Hlast = H[SA - 1];
-            } else if (F16) {
-#if IPX_STRIPE_ASM
-                // half-precision form, hand-scheduled like the integer stripe below: every operand is at least two
-                // instructions away from the packed operation that produced it, H is updated in place.
-                //   qj = diag + score of the segment about to be finished, em = its E - gapE   (prepared one block ahead)
-                //   p1 = score of the next segment                                             (prepared one block ahead)
-                if (SMAX > 0) {
-                    pk16 qj, em, p1 = 0, q2, emn, vFm, tt;
-                    qj = pkh_add(vH, pk_perm(tab1, tab0, SEL[0]));
-                    em = pkh_add(E[0], ge);
-                    if (SMAX > 1) p1 = pk_perm(tab1, tab0, SEL[SMAX > 1 ? 1 : 0]);
-                    asm volatile("s_nop 0");       // (the compiler does not see the packed reads inside the blocks: keep its last write a state away)
-                    // operands: 0 H[j], 1 E[j], 2 F, 3 p1, 4 column maximum | 5 q2, 6 em', 7 F', 8 tt (temporaries / next block's inputs) |
-                    //           9 qj, 10 em, 11 E[j+1], 12 selector of segment j+2, 13/14 score tables, 15 -gapO, 16 -gapE, 17 H[j-1]
-#define IPX_H_OPS                                                                                                              \
-                        : "+v"(H[j]), "+v"(E[j]), "+v"(vF), "+v"(p1), "+v"(cmx), "=&v"(q2), "=&v"(emn), "=&v"(vFm), "=&v"(tt)          \
-                        : "v"(qj), "v"(em), "v"(E[j + 1 < SMAX ? j + 1 : 0]), "v"(SEL[j + 2 < SMAX ? j + 2 : 0]), "v"(tab0), "v"(tab1),  \
-                          "v"(go), "v"(ge), "v"(H[j > 0 ? j - 1 : 0])
-#define IPX_H_CMX3 "v_pk_maximum3_f16 %4, %4, %17, %0\n\t"     /* column maximum: two segments at once (odd j) */
-#define IPX_H_HEAD                                                                                      \
-                        "v_pk_add_f16 %5, %0, %3\n\t"               /* q2 = H[j](old) + score[j+1]          */ \
-                        "v_pk_add_f16 %7, %2, %16\n\t"              /* F' = F - gapE                        */ \
-                        "v_pk_maximum3_f16 %0, %9, %1, %2\n\t"      /* H[j] = max3(qj, E[j], F)             */
-#define IPX_H_TAIL                                                                                      \
-                        "v_pk_maximum3_f16 %2, %7, %8, 0\n\t"       /* F = max3(F', tt, 0)                  */ \
-                        "v_pk_max_f16 %1, %10, %8"                   /* E[j] = max(em, tt)                   */
-                    IPX_UNROLL
-                    for (int j = 0; j < SMAX; ++j) {
-                        if (j + 2 < SMAX) {
-                            if (j & 1)
-                                asm volatile(IPX_H_HEAD
-                                             "v_perm_b32 %3, %14, %13, %12\n\t"          /* score[j+2], already a half */
-                                             "v_pk_add_f16 %8, %0, %15\n\t"              /* tt = H[j] - gapO           */
-                                             "v_pk_add_f16 %6, %11, %16\n\t"             /* em' = E[j+1] - gapE        */
-                                             IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
-                            else
-                                asm volatile(IPX_H_HEAD
-                                             "v_perm_b32 %3, %14, %13, %12\n\t"
-                                             "v_pk_add_f16 %8, %0, %15\n\t"
-                                             "v_pk_add_f16 %6, %11, %16\n\t"
-                                             IPX_H_TAIL IPX_H_OPS);
-                        } else if (j + 1 < SMAX) {
-                            if (j & 1)
-                                asm volatile(IPX_H_HEAD
-                                             "v_pk_add_f16 %6, %11, %16\n\t"
-                                             "v_pk_add_f16 %8, %0, %15\n\t"
-                                             IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
-                            else
-                                asm volatile(IPX_H_HEAD
-                                             "v_pk_add_f16 %6, %11, %16\n\t"
-                                             "v_pk_add_f16 %8, %0, %15\n\t"
-                                             "s_nop 0\n\t"
-                                             IPX_H_TAIL IPX_H_OPS);
-                        } else {
-                            if (j & 1)
-                                asm volatile("v_pk_maximum3_f16 %0, %9, %1, %2\n\t"
-                                             "v_pk_add_f16 %7, %2, %16\n\t"
-                                             "v_pk_add_f16 %8, %0, %15\n\t"
-                                             IPX_H_CMX3 IPX_H_TAIL IPX_H_OPS);
-                            else
-                                asm volatile("v_pk_maximum3_f16 %0, %9, %1, %2\n\t"
-                                             "v_pk_add_f16 %7, %2, %16\n\t"
-                                             "v_pk_add_f16 %8, %0, %15\n\t"
-                                             "v_pk_max_f16 %4, %4, %0\n\t"
-                                             IPX_H_TAIL IPX_H_OPS);
-                        }
-                        qj = q2; em = emn;
-                    }
-                    Hlast = H[SA - 1];
-#undef IPX_H_OPS
-#undef IPX_H_CMX3
-#undef IPX_H_HEAD
-#undef IPX_H_TAIL
-                }
-#endif
             } else if (!PERM) {
                 IPX_DP_STRIPE(pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]))
             } else if (!IPX_STRIPE_ASM || !EXACT) {
@@ -1137,6 +1148,299 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_dp_skew: the 16-bit passes (exact segLen, selector profile, half precision: see k_dp_pass PERM / F16) as a WAVEFRONT
+// over the SSE lanes.  In the striped layout lane l of a read holds rows l*S .. l*S+S-1, and the only values that cross from
+// lane l-1 to lane l inside a column are the F leaving its last row and (one column earlier) the H of that row.  k_dp_pass runs
+// all lanes on the same column, so it has to guess F = 0 at the lane boundaries and repair the column afterwards (lazy-F: a
+// max-plus scan over the lanes and one max per segment, ~50 operations per column).  Here lane l works on column t - l at
+// step t: what it needs from lane l-1 was computed one step (F, column maximum so far) or two steps (diagonal H) earlier and
+// arrives through one DPP row shift each.  No lazy-F, no group reduction for the column maximum (a running maximum travels
+// down the lanes with the column; lane 7 stores it), 7 extra steps per tile.
+//   Exactness: what this computes is the plain Gotoh recurrence -- E also sees an H that F raised across a lane boundary,
+//   which the reference's lazy-F loop never feeds back into E (ssw.c:507-518).  The H matrix is the same nevertheless (the
+//   corner "gap down, then gap right" costs what "gap right, then gap down" costs, and the reference computes the latter
+//   exactly), with gap_open > gap_ext as for every kernel without a stepped loop; every output of the pass is a function
+//   of H.  Pinned like every other kernel: bit for bit against the reference (tests/test_gpu_stress.py, the bench digests).
+//   Columns outside a read's window (before its start, the wavefront's lead-in and drain, other reads' longer windows) are
+//   given window letter 5, whose scores are -2048: H stays 0 there until real columns arrive and stays below the best after.
+//   Best score: every LANE tracks (best over its rows, first column with it, its H there); the end of the pass combines:
+//   maximum, then first column, then smallest row -- the reference's order (ssw.c:521-539, 545-556).
+// Same LDS layout, job tables and finalisation as k_dp_pass.
+// ------------------------------------------------------------------------------------------------
+template <int W> IPX_DEV pk16 group_minu(pk16 x)
+{
+    x = pk_minu(x, xl_xor1(x));
+    x = pk_minu(x, xl_xor2(x));
+    x = pk_minu(x, xl_half_mirror(x));
+    if (W == 16) x = pk_minu(x, xl_mirror(x));
+    return x;
+}
+template <int SMAX, bool REV>
+IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
+{
+    constexpr int SA = SMAX > 0 ? SMAX : 1;
+    constexpr int W = 8, G = 8, NA = 16, S = SMAX;
+    const int lane = lane_id();
+    const int g = lane / W, l = lane % W;
+    unsigned char *lds = IPX_LDS_BASE;
+    const uint32_t *tab8 = (const uint32_t *)lds;                  // [6 window letters][4 read letters]: high byte of the score as a half
+    const bool mc_lds = !REV && (pass & IPX_PASS_MC_LDS) != 0;
+    pass &= 0xFF;
+    uint32_t *maxcol = mc_lds ? (uint32_t *)(lds + 128) : b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);
+    if (lane < 24) {
+        const int v = lane < 20 ? b.mat[(lane >> 2) * 5 + (lane & 3)] : -2048;
+        ((int8_t *)lds)[lane] = (int8_t)((v == -2048 ? 0xE800u : ipx_f16_from_int(v)) >> 8);
+    }
+    IPX_SYNC();
+    const uint32_t nz = l == 0 ? 0u : 0xFFFFFFFFu;                  // what arrives from the lane above: nothing, in the first lane
+
+    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
+        if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
+        const uint32_t first = p.cls_off[cls] + want * NA;
+        const uint32_t avail = p.cls_off[cls + 1] - first;
+        const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
+
+        // ---- per-slot parameters (index 0 = low half, 1 = high half of every packed register) ----
+        int64_t job[2];
+        int L[2], ncol[2], tb[2], idx0[2], kmax[2], score1[2], rend1[2];
+        const int8_t *rd[2];
+        const uint32_t *refw[2];
+        int gO[2], gE[2];
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int slot = 2 * g + h;
+            job[h] = -1; L[h] = 0; ncol[h] = 0; tb[h] = 0; idx0[h] = 3; kmax[h] = 0; score1[h] = 0; rend1[h] = -1;
+            rd[h] = b.reads; refw[h] = (const uint32_t *)b.refs_packed; gO[h] = 1; gE[h] = 0;
+            if (slot < cnt) {
+                const int64_t jb = (int64_t)p.perm[first + slot];
+                const int rid = b.ref_id[jb];
+                const int refLen = b.ref_len[rid];
+                job[h] = jb;
+                rd[h] = b.reads + b.read_off[jb];
+                refw[h] = (const uint32_t *)(b.refs_packed + b.refp_off[rid]);
+                kmax[h] = ((refLen + 3) >> 2) + 1;
+                gO[h] = b.gap_open[jb];
+                gE[h] = b.gap_ext[jb];
+                if (!REV) {
+                    L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
+                    ncol[h] = refLen;
+                } else {
+                    const IpxResult r = b.res[jb];
+                    L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
+                    ncol[h] = r.ref_end1 + 1; if (ncol[h] < 0) ncol[h] = 0;
+                    score1[h] = r.score1;
+                    rend1[h] = r.read_end1;
+                    if (ncol[h] > 0) { idx0[h] = r.ref_end1 | 3; tb[h] = idx0[h] - r.ref_end1; }
+                }
+            }
+        }
+        {   // this kernel has no stepped lazy-F and computes in halves: refuse what would need more (host-side routing error)
+            const bool bad = (job[0] >= 0 && (gO[0] <= gE[0] || L[0] > b.f16_max_len)) || (job[1] >= 0 && (gO[1] <= gE[1] || L[1] > b.f16_max_len));
+            if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
+        }
+        const pk16 go = pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1]));     // -gapO, -gapE as halves
+        const pk16 ge = pk_make((int)ipx_f16_from_int(-gE[0]), (int)ipx_f16_from_int(-gE[1]));
+        const pk16 term = pk_make((int)ipx_f16_from_uint((uint32_t)score1[0]), (int)ipx_f16_from_uint((uint32_t)score1[1]));
+
+        // ---- selectors of the striped rows' read letters (k_dp_pass PERM) ----
+        pk16 SEL[SA];
+        {
+            int raw[2][SA];
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j) {
+                    const int r = j + l * S;                       // striped row (ssw.c:178-185)
+                    int idx = r < L[h] ? r : L[h] - 1;
+                    if (REV) idx = L[h] - 1 - idx;                 // reverse pass: seq_reverse (ssw.c:774-785)
+                    raw[h][j] = load_stream_i8(L[h] > 0 ? rd[h] + idx : (const int8_t *)b.read_off);
+                }
+            }
+            IPX_UNROLL
+            for (int j = 0; j < SMAX; ++j) {
+                const int r = j + l * S;
+                uint32_t sel = 0;
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned base = (unsigned)raw[h][j];
+                    uint32_t sh = 0x0c0cu;                         // padding row / letter N: constant 0
+                    if (r < L[h] && base < 4u) sh = 0x000cu | ((base + 4u * h) << 8);   // high byte <- table byte 4*h + base
+                    sel |= sh << (16 * h);
+                }
+                SEL[j] = sel;
+            }
+        }
+
+        // ---- DP state -----------------------------------------------------------------------------
+        pk16 H[SA], E[SA], HM[SA];
+        IPX_UNROLL
+        for (int j = 0; j < SA; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
+        pk16 Hl_cur = 0, Hl_old = 0;           // this lane's last row after the previous step / the step before
+        pk16 vFend = 0;                        // F leaving this lane's last row, previous step
+        pk16 pm = 0;                           // maximum of this lane's column over the lanes up to this one
+        pk16 lbest = 0, lcol = 0;              // per lane: best H of its rows, first column with it (counted in processing order)
+        uint32_t let = 0x0505u;                // window letters of this lane's column (low byte: low half's read), 5 = no column
+        pk16 seen = 0;                         // (reverse) this read was seen to have reached its score
+
+        const int T = (int)wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1])));
+        const int TT = T > 0 ? T + (W - 1) : 0;                    // the last lane is W-1 columns behind the first
+        uint32_t cur[2], nxt[2];
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int k0 = REV ? (idx0[h] >> 2) : 0;
+            int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
+            if (k1 < 0) k1 = 0;
+            if (k1 > kmax[h]) k1 = kmax[h];
+            cur[h] = load_global_u32(refw[h] + (k0 > kmax[h] ? kmax[h] : k0));
+            nxt[h] = load_global_u32(refw[h] + k1);
+        }
+
+        int tend = -1;                                              // (reverse) step at which every read has passed its last column
+        for (int t0 = 0; t0 < TT && (tend < 0 || t0 < tend); t0 += 4) {
+            if (t0 > 0) {
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
+                IPX_VMEM_FENCE();
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 1) : (t0 >> 2) + 1;
+                    if (k < 0) k = 0;
+                    if (k > kmax[h]) k = kmax[h];
+                    nxt[h] = load_global_u32(refw[h] + k);
+                }
+            }
+            if (REV && tend < 0) {
+                // A lane that holds the score the pass must reach got it in a column at or after the read's first such column,
+                // W-1 steps at most before every lane has been through that column: seen here, the read needs 7 more steps.
+                seen |= group_or<W>(~pk_nzmask(lbest ^ term));
+                const bool pending = (job[0] >= 0 && (seen & 0xFFFFu) == 0) || (job[1] >= 0 && (seen >> 16) == 0);
+                if (!xl_any(pending)) tend = t0 + (W - 1);
+            }
+            const int tn = t0 + 4 < TT ? t0 + 4 : TT;
+            IPX_NOUNROLL
+            for (int t = t0; t < tn; ++t) {
+                // -- the first lane's column is t: its window letters (5 outside the window); lane l takes over lane l-1's
+                const uint32_t sh = (uint32_t)(REV ? 3 - (t & 3) : (t & 3)) * 8u;
+                uint32_t nl = 0;
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    const bool valid = (uint32_t)(t - tb[h]) < (uint32_t)ncol[h];
+                    nl |= (valid ? ubfe(cur[h], sh, 8) : 5u) << (8 * h);          // always a valid letter (windows are sanitised and padded)
+                }
+                const uint32_t up = xl_row_shr1(let);
+                let = l == 0 ? nl : up;
+                const uint32_t tab0 = tab8[let & 0xFFu], tab1 = tab8[(let >> 8) & 0xFFu];
+                // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
+                const pk16 vH = xl_row_shr1(Hl_old) & nz;
+                pk16 vF = xl_row_shr1(vFend) & nz;
+                const pk16 pmu = xl_row_shr1(pm) & nz;
+                pk16 cmx = 0;
+                dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
+                vFend = vF;
+                Hl_old = Hl_cur;
+                Hl_cur = H[SA - 1];
+                pm = pk_max(cmx, pmu);                               // (non-negative halves order like integers)
+                if (!REV && l == W - 1 && t >= W - 1) {              // column t-7 is complete
+                    if (mc_lds) maxcol[(t - (W - 1)) * G + g] = pm; else store_global_u32(maxcol + ((t - (W - 1)) * G + g), pm);
+                }
+                // -- this lane's best (ssw.c:521-539, per lane)
+                const pk16 nb = pk_max(lbest, cmx);
+                const pk16 m = pk_nzmask(pk_sub(nb, lbest));         // strictly better
+                lbest = nb;
+                lcol = pk_select(m, pk_splat(t - l), lcol);
+                if (xl_any(m != 0)) {
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);
+                }
+            }
+        }
+
+        // ---- finalisation ---------------------------------------------------------------------------
+        IPX_SYNC();   // column maxima written by the last lane of each group are visible to the group
+        IPX_COMPILER_FENCE();
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int slot = 2 * g + h;
+            job[h] = -1; L[h] = 0; ncol[h] = 0; score1[h] = 0; rend1[h] = -1; idx0[h] = 3;
+            if (slot < cnt) {
+                const int64_t jb = (int64_t)p.perm[first + slot];
+                job[h] = jb;
+                if (!REV) {
+                    L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
+                    ncol[h] = b.ref_len[b.ref_id[jb]];
+                } else {
+                    const IpxResult r = b.res[jb];
+                    L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
+                    score1[h] = r.score1;
+                    rend1[h] = r.read_end1;
+                    if (r.ref_end1 + 1 > 0) idx0[h] = r.ref_end1 | 3;
+                }
+            }
+        }
+        const pk16 bestA = group_max<W>(lbest);
+        const pk16 isb = ~pk_nzmask(lbest ^ bestA);                                  // lanes holding the read's best ...
+        const pk16 cminA = group_minu<W>(pk_select(isb, lcol, 0x7FFF7FFFu));          // ... the first column any of them has it in ...
+        const pk16 isc = isb & ~pk_nzmask(lcol ^ cminA);                             // ... and the lanes that have it there
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            // end position on the read: smallest striped row holding `best` in that column (ssw.c:545-556)
+            const unsigned bh = (bestA >> (16 * h)) & 0xFFFFu;
+            const bool mine = ((isc >> (16 * h)) & 0xFFFFu) != 0;
+            uint32_t rmin = 0x7FFFFFFFu;
+            IPX_UNROLL
+            for (int j = SMAX - 1; j >= 0; --j)
+                if (mine && (((HM[j] >> (16 * h)) & 0xFFFFu) == bh)) rmin = (uint32_t)(j + l * S);
+            rmin = group_umin<W>(rmin);
+            int end_read = L[h] - 1;
+            if ((int)rmin < end_read) end_read = (int)rmin;
+            const int cfirst = (int)((cminA >> (16 * h)) & 0xFFFFu);
+            const int eref = bh == 0 ? 0 : (REV ? idx0[h] - cfirst : cfirst);       // (never improved: the initial 0, ssw.c:427)
+            const unsigned bv = ipx_f16_to_uint(bh);
+
+            if (!REV) {
+                // second best outside the mask window (ssw.c:568-581)
+                const int refLen = ncol[h];
+                const int maskLen = job[h] >= 0 ? mask_len_of(b, job[h], L[h]) : 15;
+                int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
+                int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
+                uint32_t key2 = 0xFFFFu;                              // (score2 = 0, ref_end2 = 0)
+                for (int col = l; col < refLen; col += W) {
+                    if (col < edgeL || col >= edgeR) {
+                        const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
+                        const uint32_t kk = (v << 16) | (0xFFFFu - (uint32_t)col);
+                        if (v > (key2 >> 16)) key2 = kk;
+                    }
+                }
+                key2 = group_umax<W>(key2);
+                int key = -1;                                         // pass the job takes next (plan_note below)
+                if (l == 0 && job[h] >= 0) {
+                    IpxResult r = b.res[job[h]];
+                    r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
+                    r.score1 = (uint16_t)bv;
+                    r.ref_end1 = eref;
+                    r.read_end1 = end_read;
+                    r.read_begin1 = -1;
+                    r.score2 = (uint16_t)(maskLen >= 15 ? ipx_f16_to_uint(key2 >> 16) : 0u);                    // ssw.c:864-870
+                    r.ref_end2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
+                    b.res[job[h]] = r;
+                    key = next_pass_key(b, r, L[h], false);
+                }
+                plan_note(b, key);
+            } else {
+                if (l == 0 && job[h] >= 0) {
+                    IpxResult r = b.res[job[h]];
+                    r.ref_begin1 = eref;                                                                       // ssw.c:885
+                    r.read_begin1 = rend1[h] - end_read;                                                       // ssw.c:886
+                    if ((unsigned)score1[h] > bv) r.flag = 2;                                                  // ssw.c:888-891
+                    b.res[job[h]] = r;
+                }
+            }
+        }
+    }
+}
+
 
 #if IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
@@ -1810,7 +2114,17 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_DP_EXTERN_H(W, S, REV, EX, STAGE, PERM) extern template __global__ void k_dp_pass<W, S, REV, EX, STAGE, PERM, true> IPX_DP_SIG;
 #define IPX_DP_UNIT_I(X) IPX_DP_FAMILY(X, 8, false, IPX_STAGE_EXACT, true)
 #define IPX_DP_UNIT_J(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, true)
+// the wavefront form of the same passes (k_dp_skew)
+#define IPX_SKEW_FAMILY(X, REV)                                                                                              \
+    X(0, REV) X(1, REV) X(2, REV) X(3, REV) X(4, REV) X(5, REV) X(6, REV) X(7, REV) X(8, REV) X(9, REV) X(10, REV) X(11, REV)    \
+    X(12, REV) X(13, REV) X(14, REV) X(15, REV) X(16, REV) X(17, REV) X(18, REV) X(19, REV) X(20, REV) X(21, REV) X(22, REV)     \
+    X(23, REV) X(24, REV) X(25, REV) X(26, REV) X(27, REV) X(28, REV) X(29, REV) X(30, REV) X(31, REV) X(32, REV)
+#define IPX_SKEW_DEFINE(S, REV) template __global__ void k_dp_skew<S, REV>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_SKEW_EXTERN(S, REV) extern template __global__ void k_dp_skew<S, REV>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
+#define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 #if defined(IPX_EXTERN_KERNELS)
+IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
 IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)

@@ -99,6 +99,13 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
         if constexpr (W == 8 && STAGE == IPX_STAGE_EXACT) {                                                  \
+            if (f16 && !(routing & IPX_ROUTE_NO_SKEW)) {                                                     \
+                be.note_f16(64 + N);                                                                         \
+                be.launch(IPX_KEY(kclass, cls), k_dp_skew<N, REV>, be.dp_grid(pass, cls), 64,                \
+                          ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, maxcols,           \
+                          pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0)); \
+                break;                                                                                       \
+            }                                                                                                \
             if (f16) {                                                                                       \
                 be.note_f16(N);                                                                              \
                 be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, STAGE, true, true>, be.dp_grid(pass, cls), 64, \

@@ -64,6 +64,7 @@ enum {
     IPX_ROUTE_TB_NO_FUSE = 8,      // one traceback launch per band width even for small batches
     IPX_ROUTE_NO_MC_LDS = 16,      // column maxima in the global scratch even when they would fit in LDS
     IPX_ROUTE_NO_F16 = 32,         // 16-bit passes in packed integer arithmetic even where the half-precision form applies
+    IPX_ROUTE_NO_SKEW = 64,        // half-precision 16-bit passes column by column with lazy-F (k_dp_pass) instead of as a wavefront (k_dp_skew)
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels

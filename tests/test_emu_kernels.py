@@ -281,17 +281,20 @@ def test_emu_band_doubling_stays_in_the_lane_per_job_kernels(emu, oracle_mod, po
             assert res.as_dict(i) == exp[i], (routing, i)
 
 
-def test_emu_half_precision_form_of_the_16_bit_passes(emu, oracle_mod, port):
-    """k_dp_pass F16: where every matrix entry is a half with a zero low byte and no score can pass 2047, the 16-bit passes
-    run in packed half precision (exact for these integers).  Same records as the integer form and as the oracle; matrices
-    the form cannot represent (9, 11) and reads that could score above 2047 fall back to the integer form by themselves."""
+def test_emu_half_precision_and_wavefront_forms_of_the_16_bit_passes(emu, oracle_mod, port):
+    """k_dp_pass F16 / k_dp_skew: where every matrix entry is a half with a zero low byte and no score can pass 2047, the
+    16-bit passes run in packed half precision (exact for these integers), as a wavefront over the SSE lanes (k_dp_skew) or
+    column by column (k_dp_pass F16).  Same records as the integer form and as the oracle; matrices the form cannot
+    represent (9, 11) and reads that could score above 2047 fall back to the integer form by themselves."""
     rng = np.random.default_rng(77)
     w = rng.integers(0, 4, 330).astype(np.int8)
-    reads = []
-    for i in range(24):
-        ln = int(rng.choice([40, 75, 101, 150, 151, 256]))
-        st = int(rng.integers(0, 330 - ln))
-        r = w[st:st + ln].copy()
+    w2 = rng.integers(0, 4, 97).astype(np.int8)                           # a second, much shorter window in the same tiles
+    reads, rid = [], []
+    for i in range(40):
+        win = w2 if i % 5 == 4 else w
+        ln = int(rng.choice([40, 75, 101, 150, 151, 256] if win is w else [30, 60, 90]))
+        st = int(rng.integers(0, len(win) - ln))
+        r = win[st:st + ln].copy()
         for k in np.flatnonzero(rng.random(ln) < 0.03):
             r[k] = rng.integers(0, 5)                                     # some N among them
         if i % 4 == 1:
@@ -299,22 +302,27 @@ def test_emu_half_precision_form_of_the_16_bit_passes(emu, oracle_mod, port):
         if i % 4 == 2:
             r = np.concatenate([r[:ln // 3], rng.integers(0, 4, 5).astype(np.int8), r[ln // 3:]])   # insertion
         reads.append(r)
-    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), [3, 5, 4, 12] * 6, [1, 0, 2, 3] * 6, encoded=True)
+        rid.append(1 if win is w2 else 0)
+    gos, ges = [3, 5, 4, 12, 2] * 8, [1, 0, 2, 3, 1] * 8
+    jobs = JobTable.from_sequences(reads, [w, w2], rid, gos, ges, encoded=True)
     for ms, mm, applies in ((3, 2, True), (5, 4, True), (7, 8, True), (1, 1, True), (9, 2, False), (3, 11, False), (8, 7, "short")):
         mat = oracle_mod.dna_matrix(ms, mm)
         out = []
-        for routing in (0, R.ROUTE_NO_F16):
+        for routing in (0, R.ROUTE_NO_SKEW, R.ROUTE_NO_F16):
             a = emu(0, ms, mm)
             a.set_routing(routing)
             res = a.align(jobs)
             assert a.status == 0
-            half = {k % 256 - 200 for k in a.launches if k // 256 == 0 and k % 256 >= 200}
-            if routing or applies is False:
+            col = {k % 256 - 150 for k in a.launches if k // 256 == 0 and 150 <= k % 256 < 190}
+            wav = {k % 256 - 190 for k in a.launches if k // 256 == 0 and 190 <= k % 256 < 230}
+            half = wav if routing == 0 else col
+            assert not (col if routing == 0 else wav)
+            if routing == R.ROUTE_NO_F16 or applies is False:
                 assert not half
             elif applies is True:
                 assert half >= {19, 32} or ms == 1                        # (match 1: no read leaves the 8-bit pass)
             else:
                 assert half and max(half) <= 2047 // ms // 8              # 8 x segLen x max(mat) <= 2047
             out.append(res)
-        assert all(out[0].as_dict(i) == out[1].as_dict(i) for i in range(len(reads)))
-        _compare(out[0], [(r, w, go, ge) for r, go, ge in zip(reads, [3, 5, 4, 12] * 6, [1, 0, 2, 3] * 6)], port, mat)
+        assert all(out[0].as_dict(i) == out[1].as_dict(i) == out[2].as_dict(i) for i in range(len(reads)))
+        _compare(out[0], [(r, (w, w2)[k], go, ge) for r, k, go, ge in zip(reads, rid, gos, ges)], port, mat)
