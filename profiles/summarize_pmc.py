@@ -52,6 +52,9 @@ def bench_name(k):
         else:
             base = "dp_word_rev" if rev else "dp_word_fwd"
         return "%s_%s" % (base, ("s%d" % s) if exact else "long")
+    m = re.match(r"void k_dp_skew<(\d+), (true|false)>", k)
+    if m:
+        return "%s_s%s" % ("dp_word_rev" if m.group(2) == "true" else "dp_word_fwd", m.group(1))
     m = re.match(r"void k_tb_fast<(\d+)>", k)
     if m:
         return "traceback_fast_bw%s" % m.group(1)
