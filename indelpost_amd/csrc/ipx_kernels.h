@@ -1347,8 +1347,12 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
                 }
                 // -- this lane's best (ssw.c:521-539, per lane)
                 const pk16 nb = pk_max(lbest, cmx);
-                const pk16 m = pk_nzmask(pk_sub(nb, lbest));         // strictly better
+                pk16 m = pk_nzmask(pk_sub(nb, lbest));               // strictly better
                 lbest = nb;
+                // Reverse pass: the score to reach is the maximum of this matrix (it is the forward optimum, and every local
+                // alignment inside the prefix rectangle is one of the forward matrix), so the one improvement whose column and
+                // H values are ever looked at is the one that reaches it: no bookkeeping for the others.
+                if (REV) m &= ~pk_nzmask(nb ^ term);
                 lcol = pk_select(m, pk_splat(t - l), lcol);
                 if (xl_any(m != 0)) {
                     IPX_UNROLL
@@ -1398,6 +1402,7 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
             const int cfirst = (int)((cminA >> (16 * h)) & 0xFFFFu);
             const int eref = bh == 0 ? 0 : (REV ? idx0[h] - cfirst : cfirst);       // (never improved: the initial 0, ssw.c:427)
             const unsigned bv = ipx_f16_to_uint(bh);
+            if (REV && l == 0 && job[h] >= 0 && bv != (unsigned)score1[h]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);   // (cannot happen: see the column loop)
 
             if (!REV) {
                 // second best outside the mask window (ssw.c:568-581)
