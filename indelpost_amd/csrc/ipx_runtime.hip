@@ -524,14 +524,17 @@ int ipx_pin_host(void *p, int64_t bytes)
 {
     if (!p || bytes <= 0) { set_err("ipx_pin_host: bad argument"); return IPX_ERR_ARG; }
     hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
-    if (e != hipSuccess) { set_err("hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); return IPX_ERR_NO_DEVICE; }
+    if (e != hipSuccess) { (void)hipGetLastError(); set_err("hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); return IPX_ERR_NO_DEVICE; }
     return IPX_OK;
 }
 
 int ipx_unpin_host(void *p)
 {
     if (!p) return IPX_ERR_ARG;
-    return hipHostUnregister(p) == hipSuccess ? IPX_OK : IPX_ERR_NO_DEVICE;
+    if (hipHostUnregister(p) == hipSuccess) return IPX_OK;
+    (void)hipGetLastError();                     // (HIP keeps the failure as its sticky "last error": the next launch check would report it)
+    set_err("hipHostUnregister failed: the buffer was not page-locked by ipx_pin_host");
+    return IPX_ERR_NO_DEVICE;
 }
 
 // After ipx_sync: start copying the records and the CIGAR ops of the last run into the caller's buffers on the context's

@@ -204,6 +204,8 @@ static inline int band_d(int w, int i, int j, int p) { int x = i - w; if (x < 0)
  * (len<<4|op, M=0 I=1 D=2) in *out (malloc'd) and its length; returns 0 on "trace back error".
  * Direction cells the reference would read uninitialised are zero here and take the error path.
  */
+/* test visibility: first and final band width of the last traceback on this thread's caller (diagnostics only) */
+int orc_dbg_band_first = 0, orc_dbg_band_final = 0;
 static int orc_banded_path(const int8_t *ref, const int8_t *read, int refLen, int readLen, int score,
                            int gapO, int gapE, int band_width, const int8_t *mat, int n,
                            uint32_t **out, int *outLen)
@@ -216,6 +218,7 @@ static int orc_banded_path(const int8_t *ref, const int8_t *read, int refLen, in
     int cap = 0;
     int i, j;
 
+    orc_dbg_band_first = band_width;
     do {
         width = band_width * 2 + 3;
         width_d = band_width * 2 + 1;
@@ -277,6 +280,7 @@ static int orc_banded_path(const int8_t *ref, const int8_t *read, int refLen, in
         band_width *= 2;
     } while (max < score && band_width <= len);                        /* ssw.c:669 */
     band_width /= 2;
+    orc_dbg_band_final = band_width;
 
     {   /* trace back from the bottom-right cell (ssw.c:673-733) */
         int cap_c = 16, l = 0, e = 0, plane = 2;
