@@ -1194,7 +1194,10 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
         ((int8_t *)lds)[lane] = (int8_t)((v == -2048 ? 0xE800u : ipx_f16_from_int(v)) >> 8);
     }
     IPX_SYNC();
-    const uint32_t nz = l == 0 ? 0u : 0xFFFFFFFFu;                  // what arrives from the lane above: nothing, in the first lane
+    uint32_t nz = l == 0 ? 0u : 0xFFFFFFFFu;                        // what arrives from the lane above: nothing, in the first lane
+#if !defined(IPX_CPU_EMU)
+    asm volatile("" : "+v"(nz));                                    // (kept a register: v_and_b32 costs 2 cycles, the v_cndmask_b32 on a lane mask the compiler prefers 4)
+#endif
 
     for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
         if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
@@ -1468,103 +1471,149 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
 // 255-bias the 8-bit pass overflows.  Still-unproven reads take the 8-bit pass as usual.
 // ------------------------------------------------------------------------------------------------
 #define IPX_PROVE_BAND 15
-IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap)
+#define IPX_PROVE_CHUNK 4                       // blocks of 64 consecutive jobs whose still-unproven reads share the band rounds
+// LDS: 64 B score columns | 64 * IPX_PROVE_CHUNK queue entries | read staging (lds_cap bytes)
+static inline int ipx_prove_lds_bytes(int lds_cap) { return 64 + 256 * IPX_PROVE_CHUNK + lds_cap; }
+
+// ungapped test: best run on the diagonal through the 16-bit end point (rd = the read's letters)
+IPX_DEV bool prove_ungapped(const IpxBatch &b, const IpxResult &r, const int8_t *rd, const int8_t *rf)
 {
-    // 64 consecutive jobs per wavefront: their reads are contiguous in HBM, so the wave copies them into
-    // LDS with coalesced loads and every lane then walks its own read there (the per-lane backwards byte
-    // walk straight from HBM fetched ~6 KB per read).  Batches that do not fit `lds_cap` fall back to HBM.
+    const int m = r.ref_end1 < r.read_end1 ? r.ref_end1 : r.read_end1;   // cells on the diagonal up to the end point
+    const int cap = 255 - b.bias;
+    int u = 0;
+    for (int k = m; k >= 0; --k) {
+        int a = rd[r.read_end1 - k], c = rf[r.ref_end1 - k];
+        if ((unsigned)a > 4u) a = 4;
+        u += b.mat[c * 5 + a];
+        if (u < 0) u = 0;
+        if (u >= cap) return true;
+    }
+    return false;
+}
+// gapped, banded lower bound (see above)
+IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd, const int8_t *rf, int Lr, int refLen, int go, int ge,
+                        const uint64_t *coltab)
+{
+    constexpr int BW = IPX_PROVE_BAND, HB = BW / 2;
+    const int cap = 255 - b.bias;
+    const int S8 = (Lr + 15) >> 4;                         // segLen of the 8-bit pass (ssw.c:166)
+    const int d0 = r.ref_end1 - r.read_end1;               // column - row of the end diagonal
+    bool proven = false;
+    int H[BW], F[BW];                                      // previous row: cell k is column (row + d0 - HB + k)
+    IPX_UNROLL
+    for (int k = 0; k < BW; ++k) { H[k] = 0; F[k] = 0; }
+    uint64_t win = 0;                                      // 4 bits per band cell: window letter, 7 = outside the window
+    IPX_UNROLL
+    for (int k = 0; k < BW; ++k) {
+        const int c = d0 - HB + k;
+        const uint64_t cl = (c >= 0 && c < refLen) ? (uint64_t)(uint8_t)rf[c] : 7u;
+        win |= cl << (4 * k);
+    }
+    int seg = 0;                                           // row % segLen
+    int a_next = r.read_end1 >= 0 ? rd[0] : 4;             // (rd may be HBM: the next row's letter is requested a whole row ahead)
+    for (int rr = 0; rr <= r.read_end1 && !proven; ++rr) {
+        int a = a_next;
+        a_next = rd[rr < r.read_end1 ? rr + 1 : rr];
+        if ((unsigned)a > 4u) a = 4;
+        const uint64_t row = coltab[a];
+        const bool fopen = seg != 0;                       // a vertical gap may enter this row
+        int e = 0, hleft = 0;
+        IPX_UNROLL
+        for (int k = 0; k < BW; ++k) {
+            const unsigned cl = (unsigned)(win >> (4 * k)) & 7u;
+            int f = 0;
+            if (fopen && k + 1 < BW) {
+                const int f1 = F[k + 1] - ge, f2 = H[k + 1] - go;
+                f = f1 > f2 ? f1 : f2;
+                if (f < 0) f = 0;
+            }
+            {
+                const int e1 = e - ge, e2 = hleft - go;
+                e = e1 > e2 ? e1 : e2;
+                if (e < 0) e = 0;
+            }
+            int h = H[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
+            if (h < e) h = e;
+            if (h < f) h = f;
+            if (cl > 4u) { h = 0; e = 0; f = 0; }            // outside the window
+            if (h >= cap) proven = true;
+            H[k] = h; F[k] = f; hleft = h;
+        }
+        const int cn = rr + 1 + d0 + HB;                   // column entering the band on the next row
+        const uint64_t cl = (cn >= 0 && cn < refLen) ? (uint64_t)(uint8_t)rf[cn] : 7u;
+        win = (win >> 4) | (cl << (4 * (BW - 1)));
+        if (++seg == S8) seg = 0;
+    }
+    return proven;
+}
+
+IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
+{
+    // 64 consecutive jobs per round: their reads are contiguous in HBM, so the wave copies them into LDS with coalesced loads
+    // and every lane then walks its own read there (the per-lane backwards byte walk straight from HBM fetched ~6 KB per
+    // read).  The ungapped test settles about half of the reads; a wave that ran the band for the other half with half its
+    // lanes idle would gain nothing, so the jobs still open after IPX_PROVE_CHUNK rounds are queued in LDS and the band
+    // runs on full waves of them (r02: 4 band rounds per 256 jobs -> 2 on config 2b; chunk_blocks rounds, host's choice).
     const int lane = lane_id();
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
-    int8_t *stage = (int8_t *)IPX_LDS_BASE + 64;
+    uint32_t *queue = (uint32_t *)(IPX_LDS_BASE + 64);             // jobs (index inside the chunk) waiting for the band
+    int8_t *stage = (int8_t *)IPX_LDS_BASE + 64 + 256 * IPX_PROVE_CHUNK;
     if (lane < 5) {
         uint64_t t = 0;
         for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
         coltab[lane] = t;
     }
     const int64_t nb = (b.n_jobs + 63) / 64;
-    for (int64_t blk = IPX_BID; blk < nb; blk += IPX_GDIM) {
-        const int64_t i0 = blk * 64, i = i0 + lane;
-        const int64_t i1 = i0 + 64 < b.n_jobs ? i0 + 64 : b.n_jobs;
-        const int64_t lo = b.read_off[i0], hi = b.read_off[i1];
-        const bool staged = hi - lo <= (int64_t)lds_cap;
-        IPX_SYNC();
-        if (staged) for (int64_t q = lo + lane; q < hi; q += 64) stage[q - lo] = load_stream_i8(b.reads + q);
-        IPX_SYNC();
-        int key = -1;                                              // pass the job takes next (plan_note at the end: all lanes)
-        IpxResult r;
-        r.mode = IPX_MODE_PENDING;
-        if (i < b.n_jobs) r = b.res[i];
-        if (i < b.n_jobs && r.mode == IPX_MODE_WORD_UNPROVEN) {
-        const int8_t *rd = staged ? stage + (b.read_off[i] - lo) : b.reads + b.read_off[i];
-        const int rid = b.ref_id[i];
-        const int8_t *rf = b.refs_packed + b.refp_off[rid];
-        const int m = r.ref_end1 < r.read_end1 ? r.ref_end1 : r.read_end1;   // cells on the diagonal up to the end point
-        const int cap = 255 - b.bias;
-        int u = 0;
-        bool proven = false;
-        for (int k = m; k >= 0 && !proven; --k) {
-            int a = rd[r.read_end1 - k], c = rf[r.ref_end1 - k];
-            if ((unsigned)a > 4u) a = 4;
-            u += b.mat[c * 5 + a];
-            if (u < 0) u = 0;
-            if (u >= cap) proven = true;
-        }
-        if (!proven) {
-            constexpr int BW = IPX_PROVE_BAND, HB = BW / 2;
-            const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
-            const int S8 = (Lr + 15) >> 4;                         // segLen of the 8-bit pass (ssw.c:166)
-            const int refLen = b.ref_len[rid];
-            const int d0 = r.ref_end1 - r.read_end1;               // column - row of the end diagonal
-            const int go = b.gap_open[i], ge = b.gap_ext[i];
-            int H[BW], F[BW];                                      // previous row: cell k is column (row + d0 - HB + k)
-            IPX_UNROLL
-            for (int k = 0; k < BW; ++k) { H[k] = 0; F[k] = 0; }
-            uint64_t win = 0;                                      // 4 bits per band cell: window letter, 7 = outside the window
-            IPX_UNROLL
-            for (int k = 0; k < BW; ++k) {
-                const int c = d0 - HB + k;
-                const uint64_t cl = (c >= 0 && c < refLen) ? (uint64_t)(uint8_t)rf[c] : 7u;
-                win |= cl << (4 * k);
-            }
-            int seg = 0;                                           // row % segLen
-            for (int rr = 0; rr <= r.read_end1 && !proven; ++rr) {
-                int a = rd[rr];
-                if ((unsigned)a > 4u) a = 4;
-                const uint64_t row = coltab[a];
-                const bool fopen = seg != 0;                       // a vertical gap may enter this row
-                int e = 0, hleft = 0;
-                IPX_UNROLL
-                for (int k = 0; k < BW; ++k) {
-                    const unsigned cl = (unsigned)(win >> (4 * k)) & 7u;
-                    int f = 0;
-                    if (fopen && k + 1 < BW) {
-                        const int f1 = F[k + 1] - ge, f2 = H[k + 1] - go;
-                        f = f1 > f2 ? f1 : f2;
-                        if (f < 0) f = 0;
-                    }
-                    {
-                        const int e1 = e - ge, e2 = hleft - go;
-                        e = e1 > e2 ? e1 : e2;
-                        if (e < 0) e = 0;
-                    }
-                    int h = H[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
-                    if (h < e) h = e;
-                    if (h < f) h = f;
-                    if (cl > 4u) { h = 0; e = 0; f = 0; }            // outside the window
-                    if (h >= cap) proven = true;
-                    H[k] = h; F[k] = f; hleft = h;
+    const int CB = chunk_blocks < 1 ? 1 : chunk_blocks > IPX_PROVE_CHUNK ? IPX_PROVE_CHUNK : chunk_blocks;   // (small batches: 1, for latency)
+    const int64_t nchunk = (nb + CB - 1) / CB;
+    for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
+        const int64_t cbase = chunk * CB * 64;
+        uint32_t qn = 0;                                           // queued jobs (the same in every lane)
+        for (int sb = 0; sb < CB; ++sb) {
+            const int64_t i0 = cbase + (int64_t)sb * 64, i = i0 + lane;
+            if (i0 >= b.n_jobs) break;
+            const int64_t i1 = i0 + 64 < b.n_jobs ? i0 + 64 : b.n_jobs;
+            const int64_t lo = b.read_off[i0], hi = b.read_off[i1];
+            const bool staged = hi - lo <= (int64_t)lds_cap;
+            IPX_SYNC();
+            if (staged) for (int64_t q = lo + lane; q < hi; q += 64) stage[q - lo] = load_stream_i8(b.reads + q);
+            IPX_SYNC();
+            int key = -1;                                          // pass the job takes next (plan_note: all lanes)
+            bool open = false;
+            if (i < b.n_jobs) {
+                IpxResult r = b.res[i];
+                if (r.mode == IPX_MODE_WORD_UNPROVEN) {
+                    const int8_t *rd = staged ? stage + (b.read_off[i] - lo) : b.reads + b.read_off[i];
+                    const int8_t *rf = b.refs_packed + b.refp_off[b.ref_id[i]];
+                    if (prove_ungapped(b, r, rd, rf)) {
+                        r.mode = IPX_MODE_WORD;
+                        b.res[i] = r;
+                        key = next_pass_key(b, r, (int)(b.read_off[i + 1] - b.read_off[i]), b.gap_open[i] <= b.gap_ext[i]);
+                    } else open = true;
                 }
-                const int cn = rr + 1 + d0 + HB;                   // column entering the band on the next row
-                const uint64_t cl = (cn >= 0 && cn < refLen) ? (uint64_t)(uint8_t)rf[cn] : 7u;
-                win = (win >> 4) | (cl << (4 * (BW - 1)));
-                if (++seg == S8) seg = 0;
             }
+            plan_note(b, key);
+            const uint64_t om = xl_ballot(open);
+            if (open) queue[qn + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
+            qn += (uint32_t)__builtin_popcountll(om);
         }
-        r.mode = proven ? IPX_MODE_WORD : IPX_MODE_NEED_BYTE_CHECK;
-        b.res[i] = r;
-        key = next_pass_key(b, r, (int)(b.read_off[i + 1] - b.read_off[i]), b.gap_open[i] <= b.gap_ext[i]);
+        for (uint32_t q0 = 0; q0 < qn; q0 += 64) {
+            IPX_SYNC();                                            // queue entries written; the staging area is free
+            const bool mine = q0 + (uint32_t)lane < qn;
+            const int64_t i = mine ? cbase + (int64_t)queue[q0 + lane] : 0;
+            int key = -1;
+            if (mine) {
+                IpxResult r = b.res[i];
+                const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+                const int8_t *rd = b.reads + b.read_off[i];       // straight from HBM: one letter per band row, requested a row ahead
+                const int rid = b.ref_id[i];
+                const bool proven = prove_band(b, r, rd, b.refs_packed + b.refp_off[rid], Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
+                r.mode = proven ? IPX_MODE_WORD : IPX_MODE_NEED_BYTE_CHECK;
+                b.res[i] = r;
+                key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
+            }
+            plan_note(b, key);
         }
-        plan_note(b, key);
     }
 }
 

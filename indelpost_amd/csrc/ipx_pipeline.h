@@ -25,6 +25,9 @@ struct IpxWorkspace {
     int tbf_waves, tb1_waves;
 };
 
+#ifndef IPX_PROVE_CHUNK_MIN_JOBS
+#define IPX_PROVE_CHUNK_MIN_JOBS 100000   // (the emulator build sets 0 so that its small batches take the queued form)
+#endif
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
 #define IPX_MAX_READ_LEN (8 * IPX_MAX_SEG)
@@ -226,7 +229,8 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
-        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, cap + 64, b, cap);
+        const int chunk_blocks = b.n_jobs >= IPX_PROVE_CHUNK_MIN_JOBS ? IPX_PROVE_CHUNK : 1;   // (small batches: shortest chain of rounds per wave)
+        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(cap), b, cap, chunk_blocks);
     }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         if (d.any_low)
