@@ -306,16 +306,17 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
 }
 
 
-// reads at least this long are very likely to overflow the 8-bit pass (their best possible score is
-// >= 1.4x the overflow threshold): they take the 16-bit pass first.  Any value is correct; it only
-// moves work between passes.
+// reads at least this long are likely to overflow the 8-bit pass (their best possible score is >= 1.1x the overflow
+// threshold: a 93 bp read at match 3 still overflows with five mismatches or an indel and two): they take the 16-bit pass
+// first.  Any value is correct; it only moves work between passes.  (1.4x until the 16-bit passes became the cheapest
+// kernels per read: a 100 bp read took the 8-bit lower-bound stage only to overflow there and be rescored.)
 static inline int ipx_word_first_len(const int8_t *mat, int bias)
 {
     int mx = 0;
     for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
     if (mx <= 0) return 0;
     const int cap = 255 - bias;
-    return (cap * 14 / 10 + mx - 1) / mx;
+    return (cap * 11 / 10 + mx - 1) / mx;
 }
 
 // shortest read that could overflow the 8-bit pass: len * max(mat) >= 255 - bias
