@@ -1177,9 +1177,16 @@ template <int W> IPX_DEV pk16 group_minu(pk16 x)
     if (W == 16) x = pk_minu(x, xl_mirror(x));
     return x;
 }
-template <int SMAX, bool REV>
+//   BH = the 8-bit forward pass's UPPER-BOUND stage (k_dp_pass HIGH) for reads of up to 8*SMAX bp: what that stage computes --
+//        every carry passed on -- is this same plain recurrence, whatever the striping (8 lanes here, 16 in the reference's 8-bit
+//        pass: row numbers, not lanes, enter the outputs), so it runs here at 16 reads per wave and without lazy-F.  The
+//        finalisation speaks the 8-bit pass's dialect (end_ref starts at -1, the second-best scan reaches one column further,
+//        ssw.c:220, 374) and compares with the lower-bound stage's outputs in the record, as k_dp_pass HIGH does.  `cls` is the
+//        8-bit class the pass's job list is bucketed by; its tiles hold 16 jobs.
+template <int SMAX, bool REV, bool BH = false>
 IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
 {
+    static_assert(!(BH && REV), "the upper-bound stage is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
     constexpr int W = 8, G = 8, NA = 16, S = SMAX;
     const int lane = lane_id();
@@ -1403,7 +1410,7 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
             int end_read = L[h] - 1;
             if ((int)rmin < end_read) end_read = (int)rmin;
             const int cfirst = (int)((cminA >> (16 * h)) & 0xFFFFu);
-            const int eref = bh == 0 ? 0 : (REV ? idx0[h] - cfirst : cfirst);       // (never improved: the initial 0, ssw.c:427)
+            const int eref = bh == 0 ? (BH ? -1 : 0) : (REV ? idx0[h] - cfirst : cfirst);   // (never improved: the initial 0 / -1, ssw.c:427 / 220)
             const unsigned bv = ipx_f16_to_uint(bh);
             if (REV && l == 0 && job[h] >= 0 && bv != (unsigned)score1[h]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);   // (cannot happen: see the column loop)
 
@@ -1413,6 +1420,7 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
                 const int maskLen = job[h] >= 0 ? mask_len_of(b, job[h], L[h]) : 15;
                 int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
                 int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
+                if (BH) edgeR += 1;                                   // ssw.c:374
                 uint32_t key2 = 0xFFFFu;                              // (score2 = 0, ref_end2 = 0)
                 for (int col = l; col < refLen; col += W) {
                     if (col < edgeL || col >= edgeR) {
@@ -1425,13 +1433,24 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
                 int key = -1;                                         // pass the job takes next (plan_note below)
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
-                    r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
-                    r.score1 = (uint16_t)bv;
-                    r.ref_end1 = eref;
-                    r.read_end1 = end_read;
-                    r.read_begin1 = -1;
-                    r.score2 = (uint16_t)(maskLen >= 15 ? ipx_f16_to_uint(key2 >> 16) : 0u);                    // ssw.c:864-870
-                    r.ref_end2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
+                    const uint16_t s2 = (uint16_t)(maskLen >= 15 ? ipx_f16_to_uint(key2 >> 16) : 0u);         // ssw.c:864-870
+                    const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
+                    if (BH) {
+                        // the record holds the lower-bound stage's outputs: equal outputs certify them (k_dp_pass STAGE); an upper
+                        // bound that reaches the overflow threshold certifies nothing
+                        const bool same = bv < (unsigned)(255 - b.bias) && r.score1 == (uint16_t)bv && r.ref_end1 == eref && r.read_end1 == end_read &&
+                                          r.score2 == s2 && r.ref_end2 == e2;
+                        r.mode = same ? IPX_MODE_BYTE : IPX_MODE_NEED_BYTE_EXACT;
+                        if (same) r.read_begin1 = -1;
+                    } else {
+                        r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
+                        r.score1 = (uint16_t)bv;
+                        r.ref_end1 = eref;
+                        r.read_end1 = end_read;
+                        r.read_begin1 = -1;
+                        r.score2 = s2;
+                        r.ref_end2 = e2;
+                    }
                     b.res[job[h]] = r;
                     key = next_pass_key(b, r, L[h], false);
                 }
@@ -2175,10 +2194,14 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
     X(23, REV) X(24, REV) X(25, REV) X(26, REV) X(27, REV) X(28, REV) X(29, REV) X(30, REV) X(31, REV) X(32, REV)
 #define IPX_SKEW_DEFINE(S, REV) template __global__ void k_dp_skew<S, REV>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_SKEW_EXTERN(S, REV) extern template __global__ void k_dp_skew<S, REV>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_SKEW_BH_FAMILY(X)                                                                                                \
+    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+#define IPX_SKEW_BH_DEFINE(S) template __global__ void k_dp_skew<S, false, true>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_SKEW_BH_EXTERN(S) extern template __global__ void k_dp_skew<S, false, true>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 #if defined(IPX_EXTERN_KERNELS)
-IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
+IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN)
 IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)

@@ -243,7 +243,33 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             uint8_t hs[IPX_NUM_CLASSES];                          // (fast-gap classes only: a slow-gap read is stepped, never bracketed)
             memset(hs, 0, sizeof hs);
             memcpy(hs, d.has8_low, IPX_SLOW_BASE);
-            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_HIGH], IPX_PASS_BYTE_HIGH, 8);
+            // "every carry passed on" is the plain recurrence: where halves are exact for these reads it runs as a wavefront at 16
+            // reads per wave (k_dp_skew BH, read lengths up to 256); otherwise column by column in the 8-bit layout
+            int top8 = 0;
+            for (int c = 0; c < IPX_SLOW_BASE; ++c) if (hs[c]) top8 = c;
+            const bool wave_high = ipx_perm_profile_ok(b.mat, routing) && !(routing & (IPX_ROUTE_NO_F16 | IPX_ROUTE_NO_SKEW)) &&
+                                   top8 >= 1 && top8 <= 16 && 16 * top8 <= b.f16_max_len;
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_HIGH], IPX_PASS_BYTE_HIGH, wave_high ? 16 : 8);
+            if (wave_high) {
+                const IpxPlan &ph = ws.plan[IPX_PASS_BYTE_HIGH];
+                for (int c = 1; c <= top8; ++c) {
+                    if (!hs[c]) continue;
+                    be.note_dp(IPX_KEY(IPX_K_BYTE_HIGH, c), IPX_PASS_BYTE_HIGH, c, 16);
+                    be.note_f16(64 + 2 * c);
+#define IPX_BH_CASE(C)                                                                                                    \
+    case C:                                                                                                               \
+        be.launch(IPX_KEY(IPX_K_BYTE_HIGH, c), k_dp_skew<2 * C, false, true>, be.dp_grid(IPX_PASS_BYTE_HIGH, c), 64,      \
+                  ipx_dp_lds_bytes(8, 2 * C, false, maxcols, true, routing), b, ph, c, maxcols,                           \
+                  IPX_PASS_BYTE_HIGH | (ipx_dp_mc_in_lds(8, false, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0));       \
+        break;
+                    switch (c) {
+                        IPX_BH_CASE(1) IPX_BH_CASE(2) IPX_BH_CASE(3) IPX_BH_CASE(4) IPX_BH_CASE(5) IPX_BH_CASE(6) IPX_BH_CASE(7) IPX_BH_CASE(8)
+                        IPX_BH_CASE(9) IPX_BH_CASE(10) IPX_BH_CASE(11) IPX_BH_CASE(12) IPX_BH_CASE(13) IPX_BH_CASE(14) IPX_BH_CASE(15) IPX_BH_CASE(16)
+                    default: break;
+                    }
+#undef IPX_BH_CASE
+                }
+            } else
             ipx_launch_dp<BE, 16, false, IPX_STAGE_HIGH>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], hs, maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
         }
         // reads the bracket left open: the reference's stepped lazy-F
