@@ -478,7 +478,8 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
 {
     constexpr bool LOW = STAGE == IPX_STAGE_LOW, HIGH = STAGE == IPX_STAGE_HIGH;
     static_assert(STAGE == IPX_STAGE_EXACT || (W == 16 && !REV), "the bracket stages exist for the 8-bit forward pass");
-    static_assert(!F16 || (W == 8 && PERM && EXACT && STAGE == IPX_STAGE_EXACT), "the half-precision form exists for the exact-segLen selector-profile 16-bit passes");
+    static_assert(!F16 || (PERM && EXACT && ((W == 8 && STAGE == IPX_STAGE_EXACT) || (W == 16 && STAGE == IPX_STAGE_LOW))),
+                  "the half-precision form exists for the exact-segLen selector-profile kernels without a stepped loop: 16-bit passes, 8-bit lower-bound stage");
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
     constexpr int NA = 2 * G;
@@ -578,7 +579,8 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
         const pk16 go = F16 ? pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1])) : pk_make(gO[0], gO[1]);
         const pk16 ge = F16 ? pk_make((int)ipx_f16_from_int(-gE[0]), (int)ipx_f16_from_int(-gE[1])) : pk_make(gE[0], gE[1]);
         const pk16 term = F16 ? pk_make((int)ipx_f16_from_uint((uint32_t)score1[0]), (int)ipx_f16_from_uint((uint32_t)score1[1])) : pk_make(score1[0], score1[1]);
-        const pk16 capm1 = pk_splat(255 - b.bias - 1);          // overflow when colmax >= 255-bias (ssw.c:327)
+        const pk16 capm1 = pk_splat(F16 ? (int)ipx_f16_from_uint((uint32_t)(255 - b.bias - 1)) : 255 - b.bias - 1);   // overflow when colmax >= 255-bias (ssw.c:327)
+        const pk16 capv = pk_splat(F16 ? (int)ipx_f16_from_uint((uint32_t)(255 - b.bias)) : 255 - b.bias);         // (halves: compared and stored as bit patterns)
         // closed-form lazy-F (below) applies to a read when gap_open > gap_ext
 #ifdef IPX_DEBUG_NOFAST
         const pk16 fast_static = 0;
@@ -590,7 +592,8 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
             if (F16) bad = bad || L[0] > b.f16_max_len || L[1] > b.f16_max_len;     // ... or could leave the exact range of a half
             if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
         }
-        const pk16 bigthr = pk_make(127 + gE[0], 127 + gE[1]);  // F carry > 127+gapE: signed-byte compare territory
+        const pk16 bigthr = F16 ? pk_make((int)ipx_f16_from_uint((uint32_t)(127 + gE[0])), (int)ipx_f16_from_uint((uint32_t)(127 + gE[1])))
+                                : pk_make(127 + gE[0], 127 + gE[1]);  // F carry > 127+gapE: signed-byte compare territory
         pk16 D1, D2, D4, D8;                                    // decay of a carry across 1/2/4/8 whole segments
         {
             int d[2][4];
@@ -853,9 +856,10 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                 {   // (unconditional: a carry-free column is rare, and a branch here costs a copy of every H register)
                     pk16 y;
                     if (F16) {                                  // (D1.. hold the negated decays as halves)
-                        y = xl_row_shr<1>(x); if (l < 1) y = 0; x = pkh_max(x, pkh_add(y, D1));
-                        y = xl_row_shr<2>(x); if (l < 2) y = 0; x = pkh_max(x, pkh_add(y, D2));
-                        y = xl_row_shr<4>(x); if (l < 4) y = 0; x = pkh_max(x, pkh_add(y, D4));
+                        y = xl_row_shr<1>(x); if (W == 8 && l < 1) y = 0; x = pkh_max(x, pkh_add(y, D1));
+                        y = xl_row_shr<2>(x); if (W == 8 && l < 2) y = 0; x = pkh_max(x, pkh_add(y, D2));
+                        y = xl_row_shr<4>(x); if (W == 8 && l < 4) y = 0; x = pkh_max(x, pkh_add(y, D4));
+                        if (W == 16) { y = xl_row_shr<8>(x); x = pkh_max(x, pkh_add(y, D8)); }
                     } else {
                     y = xl_row_shr<1>(x); if (W == 8 && l < 1) y = 0; x = pk_max(x, pk_subus(y, D1));
                     y = xl_row_shr<2>(x); if (W == 8 && l < 2) y = 0; x = pk_max(x, pk_subus(y, D2));
@@ -1021,7 +1025,7 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
             best = pk_select(m, nb, best);
             // on overflow the reference has already stored the saturated maximum (255-bias) in `max` when it
             // leaves, but not the column: the end-of-pass search then compares the OLD column with it
-            if (BYTE) best = pk_select(om, pk_add(capm1, 0x00010001u), best);
+            if (BYTE) best = pk_select(om, capv, best);
             endref = pk_select(m, icol, endref);
             if (xl_any(m != 0)) {
                 IPX_UNROLL
@@ -2187,6 +2191,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_DP_EXTERN_H(W, S, REV, EX, STAGE, PERM) extern template __global__ void k_dp_pass<W, S, REV, EX, STAGE, PERM, true> IPX_DP_SIG;
 #define IPX_DP_UNIT_I(X) IPX_DP_FAMILY(X, 8, false, IPX_STAGE_EXACT, true)
 #define IPX_DP_UNIT_J(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, true)
+#define IPX_DP_UNIT_M(X) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_LOW, true)          // 8-bit lower-bound stage in halves
 // the wavefront form of the same passes (k_dp_skew)
 #define IPX_SKEW_FAMILY(X, REV)                                                                                              \
     X(0, REV) X(1, REV) X(2, REV) X(3, REV) X(4, REV) X(5, REV) X(6, REV) X(7, REV) X(8, REV) X(9, REV) X(10, REV) X(11, REV)    \
@@ -2202,7 +2207,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 #if defined(IPX_EXTERN_KERNELS)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN)
-IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H)
+IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H) IPX_DP_UNIT_M(IPX_DP_EXTERN_H)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)
 #endif

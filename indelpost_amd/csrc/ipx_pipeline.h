@@ -99,18 +99,28 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
     // 16-bit passes: the half-precision form where every score of the class stays exact in a half (IpxBatch::f16_max_len)
     bool f16 = false;
     if constexpr (W == 8 && STAGE == IPX_STAGE_EXACT) f16 = perm && !slow && !(routing & IPX_ROUTE_NO_F16) && 8 * S <= b.f16_max_len;
+    if constexpr (W == 16 && STAGE == IPX_STAGE_LOW && !REV) f16 = perm && !slow && !(routing & IPX_ROUTE_NO_F16) && 16 * S <= b.f16_max_len;
 #define IPX_DP_CASE(N)                                                                                       \
     case N:                                                                                                  \
         if constexpr (W == 8 && STAGE == IPX_STAGE_EXACT) {                                                  \
             if (f16 && !(routing & IPX_ROUTE_NO_SKEW)) {                                                     \
-                be.note_f16(64 + N);                                                                         \
+                be.note_f16(1, N);                                                                         \
                 be.launch(IPX_KEY(kclass, cls), k_dp_skew<N, REV>, be.dp_grid(pass, cls), 64,                \
                           ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, maxcols,           \
                           pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0)); \
                 break;                                                                                       \
             }                                                                                                \
             if (f16) {                                                                                       \
-                be.note_f16(N);                                                                              \
+                be.note_f16(0, N);                                                                              \
+                be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, STAGE, true, true>, be.dp_grid(pass, cls), 64, \
+                          ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, cls, maxcols,      \
+                          pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0), (uint64_t)0, (uint64_t)0);  \
+                break;                                                                                       \
+            }                                                                                                \
+        }                                                                                                    \
+        if constexpr (W == 16 && STAGE == IPX_STAGE_LOW && !REV) {                                           \
+            if (f16) {                                                                                       \
+                be.note_f16(3, N);                                                                              \
                 be.launch(IPX_KEY(kclass, cls), k_dp_pass<W, N, REV, true, STAGE, true, true>, be.dp_grid(pass, cls), 64, \
                           ipx_dp_lds_bytes(W, N, REV, maxcols, true, routing), b, p, cls, cls, maxcols,      \
                           pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0), (uint64_t)0, (uint64_t)0);  \
@@ -255,7 +265,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 for (int c = 1; c <= top8; ++c) {
                     if (!hs[c]) continue;
                     be.note_dp(IPX_KEY(IPX_K_BYTE_HIGH, c), IPX_PASS_BYTE_HIGH, c, 16);
-                    be.note_f16(64 + 2 * c);
+                    be.note_f16(2, 2 * c);
 #define IPX_BH_CASE(C)                                                                                                    \
     case C:                                                                                                               \
         be.launch(IPX_KEY(IPX_K_BYTE_HIGH, c), k_dp_skew<2 * C, false, true>, be.dp_grid(IPX_PASS_BYTE_HIGH, c), 64,      \
@@ -361,15 +371,17 @@ static inline int ipx_exact_start_len(int byte_safe_len, int bracket_min_len, bo
 
 // The bracket (lower + upper bound stage) costs two closed-form passes; the stepped pass costs one plus the stepping,
 // which grows with the number of columns whose carries sit in signed-compare territory (>= 128).  A read that can only
-// just get there (best possible score below ~1.25 x 128) has few such columns and is cheaper stepped (r02: config 2a,
-// 150 bp at match 1: 360 instructions per tile column stepped vs 2 x 194 bracketed; 75 bp at match 3: 745 vs 2 x 140).
+// just get there has few such columns and is cheaper stepped.  r02, per tile column of 8 reads: config 2a (150 bp at
+// match 1) 360 instructions stepped vs 194 (lower bound) + ~110 (upper bound as a wavefront at 16 reads per wave,
+// k_dp_skew BH); 75 bp at match 3: 745 vs 140 + ~60.  With the upper bound that cheap the bracket wins from a best possible
+// score of ~130 (it was ~160 while both stages ran column by column at 8 reads per wave).
 // Any value is correct; it only moves work between passes.
 static inline int ipx_bracket_min_len(const int8_t *mat)
 {
     int mx = 0;
     for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k];
     if (mx <= 0) return 0x7FFFFFFF;
-    return (160 + mx - 1) / mx;
+    return (130 + mx - 1) / mx;
 }
 
 // longest read that may take the half-precision form of the 16-bit passes (k_dp_pass F16): every matrix entry must be a half

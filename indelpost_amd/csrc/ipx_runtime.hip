@@ -147,7 +147,7 @@ struct HipBackend {
         return (int)(g < cap ? g : cap);
     }
     void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 256 + cls) * 32 + na; }
-    void note_f16(int) {}
+    void note_f16(int, int) {}
     void copy_u32(uint32_t *dst, const uint32_t *src, int n)
     {
         hipError_t e = hipMemcpyAsync(dst, src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream);

@@ -177,6 +177,7 @@ def test_emu_routing_knobs_off(emu, golden_c, knobs):
 # kernel classes of ipx_pipeline.h (timing keys = class * 256 + job class)
 K_BYTE_LOW, K_BYTE_CHECK, K_BYTE_HIGH, K_BYTE_EXACT, K_WORD_FIRST, K_WORD_FWD, K_BYTE_REV, K_WORD_REV = range(2, 10)
 SLOW_BASE = 65
+K_PACK = 12
 
 
 def _launched(a, kclass):
@@ -213,6 +214,8 @@ def test_emu_bracket_certifies_or_steps(emu, oracle_mod, port):
         assert res.as_dict(i) == port.align(r, [w, lowc][refs_id[i]], mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])), i
     assert (res.records["mode"] == 0).all()                               # 8-bit semantics throughout
     assert _launched(a, K_BYTE_LOW) == [5] and _launched(a, K_BYTE_HIGH) == [5] and _launched(a, K_WORD_FIRST) == []
+    # both stages in halves: the lower bound column by column (marker 3), the upper bound as a wavefront at segLen 2 x 5 (marker 2)
+    assert {k % 256 for k in a.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 3 + 5, 10 + 40 * 2 + 10}
     n_low, n_high, n_exact = a.pass_jobs[1], a.pass_jobs[3], a.pass_jobs[4]
     assert n_low == 28 and n_high >= 20 and n_exact < n_high          # most of what reaches the upper-bound stage is certified
     b = emu(0, 3, 2)
@@ -313,8 +316,8 @@ def test_emu_half_precision_and_wavefront_forms_of_the_16_bit_passes(emu, oracle
             a.set_routing(routing)
             res = a.align(jobs)
             assert a.status == 0
-            col = {k % 256 - 150 for k in a.launches if k // 256 == 0 and 150 <= k % 256 < 190}
-            wav = {k % 256 - 190 for k in a.launches if k // 256 == 0 and 190 <= k % 256 < 230}
+            col = {k % 256 - 10 for k in a.launches if k // 256 == K_PACK and 10 <= k % 256 < 50}      # (markers of tests/emu: note_f16)
+            wav = {k % 256 - 50 for k in a.launches if k // 256 == K_PACK and 50 <= k % 256 < 90}
             half = wav if routing == 0 else col
             assert not (col if routing == 0 else wav)
             if routing == R.ROUTE_NO_F16 or applies is False:
