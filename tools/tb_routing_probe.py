@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Traceback routing of one batch: jobs per first band width 1..7 and jobs handed to the one-wave-per-job kernel (GpuAligner.traceback_routing)."""
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import indelpost_amd as ip
 from indelpost_amd import synth
