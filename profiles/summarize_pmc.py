@@ -52,8 +52,10 @@ def bench_name(k):
         else:
             base = "dp_word_rev" if rev else "dp_word_fwd"
         return "%s_%s" % (base, ("s%d" % s) if exact else "long")
-    m = re.match(r"void k_dp_skew<(\d+), (true|false)>", k)
+    m = re.match(r"void k_dp_skew<(\d+), (true|false)(?:, (true|false))?>", k)
     if m:
+        if m.group(3) == "true":                                   # the 8-bit upper-bound stage at segLen8 = S / 2
+            return "dp_byte_high_s%d" % (int(m.group(1)) // 2)
         return "%s_s%s" % ("dp_word_rev" if m.group(2) == "true" else "dp_word_fwd", m.group(1))
     m = re.match(r"void k_tb_fast<(\d+)>", k)
     if m:
