@@ -9,7 +9,7 @@ WL=${2:-"2b 2a 4"}
 mkdir -p $D
 python3 bench.py --steps 10 --warmup 2 > $D/bench.log 2> $D/bench.err; echo "bench rc=$?"
 for w in $WL; do
-  B="python3 bench.py --workload $w --no-subconfigs --no-cpu-baseline"
+  B="python3 bench.py --workload $w --no-subconfigs --no-cpu-baseline --no-single-stream"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/$w/kt -- $B --steps 5 --warmup 2 > $D/$w.kt.log 2> $D/$w.kt.err; echo "$w kt rc=$?"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/$w/fetch -- $B --steps 2 --warmup 1 > $D/$w.fetch.log 2> $D/$w.fetch.err; echo "$w fetch rc=$?"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/$w/write -- $B --steps 2 --warmup 1 > $D/$w.write.log 2> $D/$w.write.err; echo "$w write rc=$?"
