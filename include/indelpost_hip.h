@@ -128,7 +128,9 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
  * variant they disable has an exact fallback -- which is what the test suite uses them for:
  *   1 no 16-bit pass before the 8-bit one    2 LDS-staged profile instead of register selectors
  *   4 no upper-bound (bracket) stage         8 one traceback launch per band width
- *  16 column maxima in global scratch instead of LDS */
+ *  16 column maxima in global scratch instead of LDS
+ *  32 16-bit passes (and the 8-bit bracket stages) in packed integers even where packed halves are exact
+ *  64 half-precision passes column by column with lazy-F instead of as a wavefront over the SSE lanes */
 int ipx_set_routing(ipx_ctx *c, int flags);
 
 /* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,

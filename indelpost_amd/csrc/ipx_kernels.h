@@ -4,6 +4,8 @@
 //   k_dp_pass      <- sw_sse2_byte ssw.c:197-384 and sw_sse2_word ssw.c:410-586, forward and reverse,
 //                     including qP_byte/qP_word profile construction (ssw.c:163-188, 386-408) and
 //                     seq_reverse (ssw.c:774-785)
+//   k_dp_skew      <- the same two functions where the result is the plain recurrence (16-bit passes, 8-bit upper-bound stage):
+//                     a wavefront over the SSE lanes in packed half precision, no lazy-F
 //   k_tb_fast<BW>, k_tb_coop <- banded_sw ssw.c:588-772 (lane per job for first bands 1..7, wave per job otherwise)
 //   k_prove_overflow : nothing in the reference -- proves, from a lower bound, that the 8-bit pass (which the
 //                     reference always runs first, ssw.c:842-847) overflows, so that it need not be run
@@ -27,9 +29,9 @@
 //     (PERM; needs mat[.][N] == 0); otherwise an int8 profile [letter][j][lane][half] staged in LDS
 //     (12 KB per wave at 150 bp).  Window letters are streamed four columns per dword from 4-byte
 //     aligned, re-packed windows; per-column maxima stay in LDS when the window is short enough.
-//   * the kernels are bound by VALU issue (packed 16-bit ops issue every ~3.1-4.3 cycles per SIMD
-//     depending on the resident waves), not by latency or memory: what counts is instructions per
-//     cell and wait states between dependent packed ops -- hence the hand-scheduled stripe.
+//   * the kernels are bound by VALU issue (every packed 16-bit op costs 4 cycles per wave-instruction per SIMD,
+//     tools/ubench_issue.hip), not by latency or memory: what counts is the number of packed operations per cell
+//     -- hence the half-precision three-operand maxima, the wavefront without lazy-F and the hand-scheduled stripe.
 //   * lazy-F: a max-plus prefix scan over the lanes where that provably equals the reference's loop
 //     (gap_open > gap_ext, no carry in signed-compare territory); otherwise the reference's
 //     step-by-step loop with its data-dependent exit per read (a read that would `goto end` gets its
