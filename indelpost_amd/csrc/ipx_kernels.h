@@ -1198,7 +1198,7 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
     unsigned char *lds = IPX_LDS_BASE;
-    const uint32_t *tab8 = (const uint32_t *)lds;                  // [6 window letters][4 read letters]: high byte of the score as a half
+    // LDS offset 0: [6 window letters][4 read letters], the high byte of each score as a half; looked up by byte offset (letter x 4)
     const bool mc_lds = !REV && (pass & IPX_PASS_MC_LDS) != 0;
     pass &= 0xFF;
     uint32_t *maxcol = mc_lds ? (uint32_t *)(lds + 128) : b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);
@@ -1297,11 +1297,14 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
         pk16 vFend = 0;                        // F leaving this lane's last row, previous step
         pk16 pm = 0;                           // maximum of this lane's column over the lanes up to this one
         pk16 lbest = 0, lcol = 0;              // per lane: best H of its rows, first column with it (counted in processing order)
-        uint32_t let = 0x0505u;                // window letters of this lane's column (low byte: low half's read), 5 = no column
+        uint32_t let = 0x1414u;                // window letters of this lane's column, TIMES FOUR (= byte offsets into the score table; low byte:
+                                               //   low half's read), 5 = no column
+        pk16 ccol = pk_make(-l, -l);           // this lane's column, counted in processing order: t - l
         pk16 seen = 0;                         // (reverse) this read was seen to have reached its score
 
         const int T = (int)wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1])));
         const int TT = T > 0 ? T + (W - 1) : 0;                    // the last lane is W-1 columns behind the first
+        uint32_t pairA = 0x14141414u, pairB = 0x14141414u;         // letters (x 4) of the first lane's next four columns: bytes (half 0, half 1) x 2 each
         uint32_t cur[2], nxt[2];
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
@@ -1334,20 +1337,37 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
                 const bool pending = (job[0] >= 0 && (seen & 0xFFFFu) == 0) || (job[1] >= 0 && (seen >> 16) == 0);
                 if (!xl_any(pending)) tend = t0 + (W - 1);
             }
+            {   // the four columns of this group as the first lane will see them: letter x 4 (always a valid letter: windows are
+                // sanitised and padded), 5 x 4 outside the read's window; interleaved so that one v_perm_b32 per step picks a column
+                uint32_t x[2];
+                bool inside = true;                                  // all four columns inside both windows (the usual group)
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    x[h] = cur[h] << 2;
+                    inside = inside && t0 >= tb[h] && t0 + 4 <= tb[h] + ncol[h];
+                }
+                if (xl_any(!inside)) {
+                    IPX_UNROLL
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t vm = 0;
+                        IPX_UNROLL
+                        for (int k = 0; k < 4; ++k)
+                            if ((uint32_t)(t0 + k - tb[h]) < (uint32_t)ncol[h]) vm |= 0xFFu << (8 * (REV ? 3 - k : k));
+                        x[h] = (x[h] & vm) | (0x14141414u & ~vm);
+                    }
+                }
+                pairA = pk_perm(x[1], x[0], REV ? 0x06020703u : 0x05010400u);
+                pairB = pk_perm(x[1], x[0], REV ? 0x04000501u : 0x07030602u);
+            }
             const int tn = t0 + 4 < TT ? t0 + 4 : TT;
             IPX_NOUNROLL
             for (int t = t0; t < tn; ++t) {
-                // -- the first lane's column is t: its window letters (5 outside the window); lane l takes over lane l-1's
-                const uint32_t sh = (uint32_t)(REV ? 3 - (t & 3) : (t & 3)) * 8u;
-                uint32_t nl = 0;
-                IPX_UNROLL
-                for (int h = 0; h < 2; ++h) {
-                    const bool valid = (uint32_t)(t - tb[h]) < (uint32_t)ncol[h];
-                    nl |= (valid ? ubfe(cur[h], sh, 8) : 5u) << (8 * h);          // always a valid letter (windows are sanitised and padded)
-                }
+                // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
+                const uint32_t ksel = (t & 1) ? 0x0c0c0302u : 0x0c0c0100u;
+                const uint32_t nl = pk_perm(0u, (t & 2) ? pairB : pairA, ksel);
                 const uint32_t up = xl_row_shr1(let);
                 let = l == 0 ? nl : up;
-                const uint32_t tab0 = tab8[let & 0xFFu], tab1 = tab8[(let >> 8) & 0xFFu];
+                const uint32_t tab0 = *(const uint32_t *)(lds + (let & 0xFFu)), tab1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
                 // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
                 const pk16 vH = xl_row_shr1(Hl_old) & nz;
                 pk16 vF = xl_row_shr1(vFend) & nz;
@@ -1363,17 +1383,21 @@ IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b
                 }
                 // -- this lane's best (ssw.c:521-539, per lane)
                 const pk16 nb = pk_max(lbest, cmx);
-                pk16 m = pk_nzmask(pk_sub(nb, lbest));               // strictly better
+                const pk16 dif = nb ^ lbest;                         // a half that is not 0: strictly better
                 lbest = nb;
-                // Reverse pass: the score to reach is the maximum of this matrix (it is the forward optimum, and every local
-                // alignment inside the prefix rectangle is one of the forward matrix), so the one improvement whose column and
-                // H values are ever looked at is the one that reaches it: no bookkeeping for the others.
-                if (REV) m &= ~pk_nzmask(nb ^ term);
-                lcol = pk_select(m, pk_splat(t - l), lcol);
-                if (xl_any(m != 0)) {
-                    IPX_UNROLL
-                    for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);
+                if (xl_any(dif != 0)) {
+                    pk16 m = pk_nzmask(dif);
+                    // Reverse pass: the score to reach is the maximum of this matrix (it is the forward optimum, and every local
+                    // alignment inside the prefix rectangle is one of the forward matrix), so the one improvement whose column and
+                    // H values are ever looked at is the one that reaches it: no bookkeeping for the others.
+                    if (REV) m &= ~pk_nzmask(nb ^ term);
+                    if (!REV || xl_any(m != 0)) {
+                        lcol = pk_select(m, ccol, lcol);
+                        IPX_UNROLL
+                        for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);
+                    }
                 }
+                ccol = pk_add(ccol, 0x00010001u);
             }
         }
 
