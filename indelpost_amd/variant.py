@@ -68,15 +68,13 @@ class Variant:
 
     @staticmethod
     def _format_chrom_name(chrom, reference):                       # variant.pyx:119-138
+        """the name in the FASTA's own convention: with or without "chr", mitochondrion as M or MT"""
         names = reference.references
-        prefixed = names[0].startswith("chr")
-        has_mt = "chrMT" in names or "MT" in names
-        chrom = chrom.replace("chr", "")
-        if chrom == "M" and has_mt:
-            chrom = "MT"
-        elif chrom == "MT" and not has_mt:
-            chrom = "M"
-        return "chr" + chrom if prefixed else chrom
+        bare = chrom.replace("chr", "")
+        mt_style = any(n in ("chrMT", "MT") for n in names)
+        if bare in ("M", "MT"):
+            bare = "MT" if mt_style else "M"
+        return ("chr" + bare) if names[0].startswith("chr") else bare
 
     def _validate(self):                                            # variant.pyx:140-160
         if not self.ref or not self.alt:
@@ -150,64 +148,69 @@ class Variant:
 
     def normalize(self, inplace=False):
         """left-align (up to 300 bases) and trim to the minimal representation (variant.pyx:276-324)"""
-        i = self if inplace else Variant(self.chrom, self.pos, self.ref, self.alt, self.reference, skip_validation=True)
-        lhs = i.reference.fetch(i.chrom, max(0, i.pos - 1 - 300), i.pos - 1)[::-1]
-        n = 0
-        while i.ref[-1].upper() == i.alt[-1].upper() != "N" and n < len(lhs):
-            i.ref = lhs[n] + i.ref[:-1]
-            i.alt = lhs[n] + i.alt[:-1]
-            i.pos -= 1
-            n += 1
-        while i.ref[0].upper() == i.alt[0].upper() and len(i.ref) > 1 and len(i.alt) > 1:
-            i.ref = i.ref[1:]
-            i.alt = i.alt[1:]
-            i.pos += 1
-        return None if inplace else i
+        where, r, a = self.pos, self.ref, self.alt
+        upstream = self.reference.fetch(self.chrom, max(0, where - 301), where - 1)
+        # roll left while both alleles end in the same (non-N) base: drop it, prepend the base before the variant
+        steps = 0
+        while steps < len(upstream) and r[-1].upper() == a[-1].upper() != "N":
+            prev = upstream[len(upstream) - 1 - steps]
+            r, a = prev + r[:-1], prev + a[:-1]
+            where -= 1
+            steps += 1
+        # trim the shared prefix down to one padding base
+        while min(len(r), len(a)) > 1 and r[0].upper() == a[0].upper():
+            r, a, where = r[1:], a[1:], where + 1
+        if inplace:
+            self.pos, self.ref, self.alt = where, r, a
+            return None
+        return Variant(self.chrom, where, r, a, self.reference, skip_validation=True)
 
     def generate_equivalents(self):
         """the normalised object and its right-shifted equivalents (variant.pyx:327-371)"""
-        i = Variant(self.chrom, self.pos, self.ref, self.alt, self.reference, skip_validation=True).normalize()
-        pos, ref, alt, is_ins = i.pos, i.ref, i.alt, i.is_ins
-        res = [i]
-        if not i.is_indel:
-            return res
-        window = 300
-        rt_flank = i._right_of_event(window)
-        n = 0
-        while self == i and n < window:
-            right_base = rt_flank[n]
-            if is_ins:
-                ref = alt[1]
-                alt = alt[1:] + right_base
-            else:
-                alt = ref[1]
-                ref = ref[1:] + right_base
-            pos += 1
-            i = Variant(self.chrom, pos, ref, alt, self.reference, skip_validation=True)
-            if self == i:
-                res.append(i)
-            n += 1
-        return res
+        first = self.normalize()
+        found = [first]
+        if not first.is_indel:
+            return found
+        limit = 300
+        downstream = first._right_of_event(limit)
+        where, r, a, insertion = first.pos, first.ref, first.alt, first.is_ins
+        cand = first
+        for k in range(limit):
+            if not (self == cand):                 # (the reference's loop condition: stops after the first shift that is no equivalent)
+                break
+            nxt = downstream[k]
+            if insertion:                          # slide the inserted string one base to the right
+                r, a = a[1], a[1:] + nxt
+            else:                                  # slide the deleted string
+                a, r = r[1], r[1:] + nxt
+            where += 1
+            cand = Variant(self.chrom, where, r, a, self.reference, skip_validation=True)
+            if self == cand:
+                found.append(cand)
+        return found
+
+    def _clone(self, pos=None, ref=None, alt=None):
+        return Variant(self.chrom, self.pos if pos is None else pos, self.ref if ref is None else ref,
+                       self.alt if alt is None else alt, self.reference, skip_validation=True)
 
     def _generate_equivalents_private(self):
-        if self.is_non_complex_indel():
-            return self.generate_equivalents()
-        # a complex indel is pinned at the start and at the end of the deleted sequence
-        return [Variant(self.chrom, self.pos, self.ref, self.alt, self.reference, skip_validation=True),
-                Variant(self.chrom, self.pos + len(self.ref), self.ref, self.alt, self.reference, skip_validation=True)]
+        """(variant.pyx:374-384) a complex indel is pinned at the start and at the end of the deleted sequence"""
+        return self.generate_equivalents() if self.is_non_complex_indel() else [self._clone(), self._clone(pos=self.pos + len(self.ref))]
 
     def _get_indel_seq(self, how=None):
+        """(variant.pyx:386-393)"""
         if self.is_non_complex_indel():
             return self.indel_seq
-        return self.alt[1:] if how == "I" else self.ref[1:] if how == "D" else None
+        return {"I": self.alt[1:], "D": self.ref[1:]}.get(how)
 
     def _reduce_complex_indel(self, to=None):
+        """(variant.pyx:395-401) the insertion or the deletion half of a complex indel; NullVariant for a non-complex one"""
         if self.is_non_complex_indel():
             return NullVariant(self.chrom, self.pos, self.reference)
         if to == "I":
-            return Variant(self.chrom, self.pos, self.alt[0], self.alt, self.reference, skip_validation=True)
+            return self._clone(ref=self.alt[0])
         if to == "D":
-            return Variant(self.chrom, self.pos, self.ref, self.ref[0], self.reference, skip_validation=True)
+            return self._clone(alt=self.ref[0])
         return None
 
     def query_vcf(self, *a, **k):
@@ -248,20 +251,23 @@ class Variant:
         if self.is_non_complex_indel():
             return [self]
         from .localn import align, make_aligner
-        var = Variant(self.chrom, self.pos, self.ref, self.alt, self.reference, skip_validation=True).normalize()
-        lt_pos, rt_pos, window = var.pos - 1, var.pos - 1 + len(var.ref), 100
-        mut_seq = self.reference.fetch(var.chrom, lt_pos - window, lt_pos) + var.alt + self.reference.fetch(var.chrom, rt_pos, rt_pos + window)
-        ref_seq = self.reference.fetch(var.chrom, lt_pos - window, lt_pos + len(var.ref) + window)
-        aln = align(make_aligner(ref_seq, match_score, mismatch_penalty), mut_seq, gap_open_penalty, gap_extension_penalty)
-        indels, snvs = findall_indels(aln, lt_pos + 1 - window + aln.reference_start, ref_seq, mut_seq, report_snvs=True)
-        out = []
+        v = self.normalize()
+        flank = 100
+        left_end = v.pos - 1                                   # 0-based end of the left flank
+        right_start = left_end + len(v.ref)
+        fa, chrom = self.reference, v.chrom
+        upstream = fa.fetch(chrom, left_end - flank, left_end)
+        mutated = upstream + v.alt + fa.fetch(chrom, right_start, right_start + flank)
+        original = fa.fetch(chrom, left_end - flank, right_start + flank)
+        aln = align(make_aligner(original, match_score, mismatch_penalty), mutated, gap_open_penalty, gap_extension_penalty)
+        indels, snvs = findall_indels(aln, left_end + 1 - flank + aln.reference_start, original, mutated, report_snvs=True)
+        parts = []
         for d in indels:
             pad = d["lt_ref"][-1]
             ref, alt = (pad + d["del_seq"], pad) if d["indel_type"] == "D" else (pad, pad + d["indel_seq"])
-            out.append(Variant(self.chrom, d["pos"], ref, alt, self.reference, skip_validation=True))
-        for v in snvs:
-            out.append(Variant(self.chrom, v["pos"], v["ref"], v["alt"], self.reference, skip_validation=True))
-        return out
+            parts.append(self._clone(pos=d["pos"], ref=ref, alt=alt))
+        parts.extend(self._clone(pos=x["pos"], ref=x["ref"], alt=x["alt"]) for x in snvs)
+        return parts
 
     def __repr__(self):
         return "Variant(%r, %d, %r, %r)" % (self.chrom, self.pos, self.ref, self.alt)
