@@ -333,14 +333,18 @@ IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass, int na)
 // entering segment 0 on entry and F leaving the last segment on exit, cmx = maximum of the new H with the cmx passed in.
 // go / ge hold -gapO / -gapE as halves, tab0 / tab1 the score tables of the two window letters, SEL the selectors.
 // ------------------------------------------------------------------------------------------------
-template <int SMAX>
+// MID > 0: the lane's segments are TWO of the reference's lanes (k_dp_pass VL2): F starts again from 0 at segment MID, and the F
+// that left segment MID-1 is returned in *fmid.
+template <int SMAX, int MID = 0>
 IPX_DEV void dp_stripe_f16(pk16 (&H)[SMAX > 0 ? SMAX : 1], pk16 (&E)[SMAX > 0 ? SMAX : 1], const pk16 (&SEL)[SMAX > 0 ? SMAX : 1],
-                           pk16 &vF, pk16 &cmx, pk16 vH, const uint32_t tab0, const uint32_t tab1, const pk16 go, const pk16 ge)
+                           pk16 &vF, pk16 &cmx, pk16 vH, const uint32_t tab0, const uint32_t tab1, const pk16 go, const pk16 ge,
+                           pk16 *fmid = nullptr)
 {
 #if !IPX_STRIPE_ASM
     // plain form (emulator)
     IPX_UNROLL
     for (int j = 0; j < SMAX; ++j) {
+        if (MID > 0 && j == MID) { *fmid = vF; vF = 0; }
         const pk16 h = pkh_max3(pkh_add(vH, pk_perm(tab1, tab0, SEL[j])), E[j], vF);
         cmx = pkh_max(cmx, h);
         vH = H[j];
@@ -376,6 +380,7 @@ IPX_DEV void dp_stripe_f16(pk16 (&H)[SMAX > 0 ? SMAX : 1], pk16 (&E)[SMAX > 0 ? 
             "v_pk_max_f16 %1, %10, %8"                   /* E[j] = max(em, tt)                   */
         IPX_UNROLL
         for (int j = 0; j < SMAX; ++j) {
+            if (MID > 0 && j == MID) { *fmid = vF; vF = 0; asm volatile("s_nop 0"); }
             if (j + 2 < SMAX) {
                 if (j & 1)
                     asm volatile(IPX_H_HEAD
@@ -475,17 +480,18 @@ IPX_HD constexpr int ipx_dp_perm_waves(int smax)
     const int w = 512 / (4 * smax + 90);
     return w < 1 ? 1 : w;
 }
-template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false, bool F16 = false>
-IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow)
+template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false, bool F16 = false, bool VL2 = false>
+IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow)
 {
     constexpr bool LOW = STAGE == IPX_STAGE_LOW, HIGH = STAGE == IPX_STAGE_HIGH;
-    static_assert(STAGE == IPX_STAGE_EXACT || (W == 16 && !REV), "the bracket stages exist for the 8-bit forward pass");
-    static_assert(!F16 || (PERM && EXACT && ((W == 8 && STAGE == IPX_STAGE_EXACT) || (W == 16 && STAGE == IPX_STAGE_LOW))),
+    static_assert(STAGE == IPX_STAGE_EXACT || ((W == 16 || VL2) && !REV), "the bracket stages exist for the 8-bit forward pass");
+    static_assert(!VL2 || (W == 8 && F16 && STAGE == IPX_STAGE_LOW && SMAX % 2 == 0), "two reference lanes per GPU lane: the half-precision lower-bound stage");
+    static_assert(!F16 || (PERM && EXACT && ((W == 8 && STAGE == IPX_STAGE_EXACT) || ((W == 16 || VL2) && STAGE == IPX_STAGE_LOW))),
                   "the half-precision form exists for the exact-segLen selector-profile kernels without a stepped loop: 16-bit passes, 8-bit lower-bound stage");
     constexpr int SA = SMAX > 0 ? SMAX : 1;            // array extent (segLen 0 = empty read)
     constexpr int G = 64 / W;
     constexpr int NA = 2 * G;
-    constexpr bool BYTE = (W == 16);
+    constexpr bool BYTE = (W == 16) || VL2;            // 8-bit semantics (VL2: in the 8-lane layout, see below)
     // the reference's step-by-step lazy-F loop is needed for reads with gap_open <= gap_ext and, in the exact
     // 8-bit passes, for carries in signed-compare territory.  The selector-profile kernels of the 16-bit passes
     // and of the lower-bound stage leave it out (the host launches them only when no job has gap_open <= gap_ext):
@@ -608,6 +614,13 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                 }
             D1 = pk_make(d[0][0], d[1][0]); D2 = pk_make(d[0][1], d[1][1]);
             D4 = pk_make(d[0][2], d[1][2]); D8 = pk_make(d[0][3], d[1][3]);
+        }
+        pk16 Dh = 0;                                            // VL2: decay across ONE reference lane = half a GPU lane's segments
+        if (VL2) {
+            int v[2];
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) { v[h] = (S / 2) * gE[h]; v[h] = (int)ipx_f16_from_int(-(v[h] > 2047 ? 2047 : v[h])); }
+            Dh = pk_make(v[0], v[1]);
         }
 
         // ---- stage the tile's query profile in LDS: int8 [5 letters][S][64 lanes][2 halves] ------------
@@ -757,8 +770,9 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
                     vF = pk_max(vF, tt);                                                                     \
                 }                                                                                            \
             }
+            pk16 fmid = 0;                                          // VL2: F that left the lane's first reference lane
             if constexpr (F16) {
-                dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
+                dp_stripe_f16<SMAX, VL2 ? SMAX / 2 : 0>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge, &fmid);
                 Hlast = H[SA - 1];
             } else if (!PERM) {
                 IPX_DP_STRIPE(pk_lo16_pair((uint32_t)(int)pa0[j * 128], (uint32_t)(int)pa1[j * 128]))
@@ -840,7 +854,36 @@ IPX_KERNEL_WAVE_OCC((PERM && REV) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(
             //   C_l = max_k sat(Fend[l-1-k] - k*segLen*gapE),   H[l][j] = max(H[l][j], sat(C_l - j*gapE)),
             // done here with log2(W) DPP row shifts.  Reads outside that regime fall through to the
             // reference's step-by-step loop below with its per-read, data-dependent exit.
-            {
+            if constexpr (VL2) {
+                // Two reference lanes per GPU lane: the lane's first SMAX/2 segments are SSE lane 2l (its F left as fmid), the
+                // rest SSE lane 2l+1 (F left as vF), so the rows sit exactly where the 8-lane layout puts them and only the
+                // carries differ: into lane 2l comes what left lane 2l-1 (the GPU lane above), into lane 2l+1 what left lane
+                // 2l (this GPU lane).  What leaves a GPU lane downwards when nothing comes in is inj = max(F_B, F_A - D);
+                // the scan over the GPU lanes is the usual one with twice the decay.
+                pk16 cA = fmid, cB = vF;
+                const pk16 big = pk_nzmask(pk_subus(cA, bigthr)) | pk_nzmask(pk_subus(cB, bigthr));
+                const pk16 anybig = group_or<W>(big);
+                const pk16 drop = anybig & fast_static;              // LOW: no lazy-F at all in such a column (see STAGE)
+                cA &= ~drop; cB &= ~drop; dropped |= drop;
+                cA &= fast_static; cB &= fast_static;
+                pk16 x = xl_row_shr1(pkh_max(cB, pkh_add(cA, Dh)));
+                if (l == 0) x = 0;
+                pk16 y;
+                y = xl_row_shr<1>(x); if (l < 1) y = 0; x = pkh_max(x, pkh_add(y, D1));
+                y = xl_row_shr<2>(x); if (l < 2) y = 0; x = pkh_max(x, pkh_add(y, D2));
+                y = xl_row_shr<4>(x); if (l < 4) y = 0; x = pkh_max(x, pkh_add(y, D4));
+                const pk16 xb = pkh_max(cA, pkh_add(x, Dh));         // carry into the second reference lane of this GPU lane
+                cmx = pk_max(cmx, pk_max(x, xb));                    // (all non-negative: halves order like integers)
+                pk16 a = x;
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j) {
+                    if (j == SMAX / 2) a = xb;
+                    H[j] = pkh_max(H[j], a);
+                    a = pkh_add(a, ge);
+                }
+                Hlast = H[SA - 1];
+                vF = 0;
+            } else {
                 pk16 fe = fast_static;
                 if (BYTE) {
                     const pk16 big = pk_nzmask(pk_subus(vF, bigthr));
@@ -2218,6 +2261,10 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_DP_UNIT_I(X) IPX_DP_FAMILY(X, 8, false, IPX_STAGE_EXACT, true)
 #define IPX_DP_UNIT_J(X) IPX_DP_FAMILY(X, 8, true, IPX_STAGE_EXACT, true)
 #define IPX_DP_UNIT_M(X) IPX_DP_FAMILY(X, 16, false, IPX_STAGE_LOW, true)          // 8-bit lower-bound stage in halves
+// ... and with two reference lanes per GPU lane (VL2): 8-bit classes 0..16 = 0, 2, .., 32 segments in the 8-lane layout
+#define IPX_VL2_FAMILY(X) X(0) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+#define IPX_VL2_DEFINE(S) template __global__ void k_dp_pass<8, S, false, true, IPX_STAGE_LOW, true, true, true> IPX_DP_SIG;
+#define IPX_VL2_EXTERN(S) extern template __global__ void k_dp_pass<8, S, false, true, IPX_STAGE_LOW, true, true, true> IPX_DP_SIG;
 // the wavefront form of the same passes (k_dp_skew)
 #define IPX_SKEW_FAMILY(X, REV)                                                                                              \
     X(0, REV) X(1, REV) X(2, REV) X(3, REV) X(4, REV) X(5, REV) X(6, REV) X(7, REV) X(8, REV) X(9, REV) X(10, REV) X(11, REV)    \
@@ -2233,7 +2280,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 #if defined(IPX_EXTERN_KERNELS)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN)
-IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H) IPX_DP_UNIT_M(IPX_DP_EXTERN_H)
+IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H) IPX_DP_UNIT_M(IPX_DP_EXTERN_H) IPX_VL2_FAMILY(IPX_VL2_EXTERN)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)
 #endif

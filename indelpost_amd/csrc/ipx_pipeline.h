@@ -82,6 +82,18 @@ static inline bool ipx_perm_profile_ok(const int8_t *mat, int routing)
     return !(routing & IPX_ROUTE_NO_PERM_PROFILE) && mat[4] == 0 && mat[9] == 0 && mat[14] == 0 && mat[19] == 0 && mat[24] == 0;
 }
 
+// The 8-bit lower-bound stage at 16 reads per wave (k_dp_pass VL2: two reference lanes per GPU lane, computed in halves): when the
+// register-selector profile and exact halves apply to every 8-bit class of the batch, none of them is a slow-gap class (those
+// need the stepped kernels, whose tiles hold 8 reads: a pass has ONE tile size) and reads are at most 256 bp.
+static inline bool ipx_low2_ok(const IpxBatch &b, const IpxDims &d, int routing)
+{
+    if (!ipx_perm_profile_ok(b.mat, routing) || (routing & (IPX_ROUTE_NO_F16 | IPX_ROUTE_NO_VL2))) return false;
+    int top = 0;
+    for (int c = 0; c < IPX_NUM_CLASSES; ++c)
+        if (d.has8_low[c] || d.has8_wf[c]) { if (c >= IPX_SLOW_BASE) return false; top = c; }
+    return top >= 1 && top <= 16 && 16 * top <= b.f16_max_len;
+}
+
 // timing key of a launch: kernel class * 256 + sub (DP kernels: sub = class, IPX_SUB_GENERIC = long-read / sweep kernel)
 #define IPX_KEY(kclass, sub) ((kclass) * 256 + (sub))
 #define IPX_NUM_KEYS (IPX_K_NUM * 256)
@@ -118,6 +130,15 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
                 break;                                                                                       \
             }                                                                                                \
         }                                                                                                    \
+        if constexpr (W == 16 && STAGE == IPX_STAGE_LOW && !REV && (N) <= 16) {                              \
+            if (f16 && (routing & IPX_ROUTE_INTERNAL_VL2)) {                                                 \
+                be.note_f16(4, N);                                                                           \
+                be.launch(IPX_KEY(kclass, cls), k_dp_pass<8, 2 * (N), false, true, IPX_STAGE_LOW, true, true, true>, be.dp_grid(pass, cls), 64, \
+                          ipx_dp_lds_bytes(8, 2 * (N), false, maxcols, true, routing), b, p, cls, cls, maxcols, \
+                          pass | (ipx_dp_mc_in_lds(8, false, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0), (uint64_t)0, (uint64_t)0);  \
+                break;                                                                                       \
+            }                                                                                                \
+        }                                                                                                    \
         if constexpr (W == 16 && STAGE == IPX_STAGE_LOW && !REV) {                                           \
             if (f16) {                                                                                       \
                 be.note_f16(3, N);                                                                              \
@@ -136,7 +157,7 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
                       ipx_dp_lds_bytes(W, N, REV, maxcols, false, routing), b, p, cls, cls, maxcols, pass,   \
                       (uint64_t)0, (uint64_t)0);                                                             \
         break;
-    be.note_dp(IPX_KEY(kclass, cls), pass, cls, 128 / W);
+    be.note_dp(IPX_KEY(kclass, cls), pass, cls, (W == 16 && STAGE == IPX_STAGE_LOW && !REV && f16 && S <= 16 && (routing & IPX_ROUTE_INTERNAL_VL2)) ? 16 : 128 / W);
     switch (S) {
         IPX_DP_CASE(0) IPX_DP_CASE(1) IPX_DP_CASE(2) IPX_DP_CASE(3) IPX_DP_CASE(4) IPX_DP_CASE(5) IPX_DP_CASE(6)
         IPX_DP_CASE(7) IPX_DP_CASE(8) IPX_DP_CASE(9) IPX_DP_CASE(10) IPX_DP_CASE(11) IPX_DP_CASE(12) IPX_DP_CASE(13)
@@ -207,13 +228,14 @@ static inline uint32_t *ipx_plan_count_of(uint32_t *tables, int pass) { return t
 // The job lists of the passes a job starts in (every record PENDING): they depend on the read lengths, the penalties
 // and the scoring parameters only, so they are built when a batch (or the parameters) changed, not in every run.
 template <class BE>
-static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace &ws)
+static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing)
 {
+    const int na_low = ipx_low2_ok(b, d, routing) ? 16 : 8;      // tile size of the lower-bound stage (ipx_run_pipeline uses the same rule)
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, 0), IPX_FIRST_DYNAMIC_PASS * 2 * IPX_NUM_CLASSES);
     if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, 16, true);
     if (b.score_size != 1) {
-        ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW], IPX_PASS_BYTE_LOW, 8, true);
+        ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW], IPX_PASS_BYTE_LOW, na_low, true);
         // jobs that start in the stepped pass: counted now, their count seeds that pass's (dynamic) row in every run
         be.zero_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, IPX_NUM_CLASSES);
         be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, (int)IPX_PASS_BYTE_EXACT);
@@ -233,6 +255,8 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, IPX_FIRST_DYNAMIC_PASS), (IPX_NUM_PASSES - IPX_FIRST_DYNAMIC_PASS) * 2 * IPX_NUM_CLASSES);
     if (b.score_size != 1) be.copy_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, ws.exact_starters, IPX_NUM_CLASSES);
 
+    const bool low2 = ipx_low2_ok(b, d, routing);                 // 8-bit lower-bound launches: 16 reads per wave (k_dp_pass VL2)
+    if (low2) routing |= IPX_ROUTE_INTERNAL_VL2;
     const bool wf = b.score_size == 2 && d.any_wf;
     if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
@@ -246,7 +270,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         if (d.any_low)
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW], d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_LOW, routing);
         if (wf) {                                                // word-first reads whose overflow could not be proven
-            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, 8);
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
         }
         if (b.use_bracket && d.any_low) {                        // upper-bound stage: certifies the lower-bound outputs or not

@@ -442,7 +442,7 @@ int ipx_run(ipx_ctx *c)
         ipx_dims_finish(c->dims, b.word_first_len, c->score_size, ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
         const bool prof = c->profiling;
         c->profiling = false;
-        ipx_build_static_plans(be, b, c->ws);
+        ipx_build_static_plans(be, b, c->ws, c->dims, c->routing);
         c->profiling = prof;
         c->static_valid = true;
     }

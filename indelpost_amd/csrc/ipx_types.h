@@ -65,6 +65,9 @@ enum {
     IPX_ROUTE_NO_MC_LDS = 16,      // column maxima in the global scratch even when they would fit in LDS
     IPX_ROUTE_NO_F16 = 32,         // 16-bit passes in packed integer arithmetic even where the half-precision form applies
     IPX_ROUTE_NO_SKEW = 64,        // half-precision 16-bit passes column by column with lazy-F (k_dp_pass) instead of as a wavefront (k_dp_skew)
+    IPX_ROUTE_NO_VL2 = 128,        // 8-bit lower-bound stage in the reference's 16-lane layout (8 reads per wave) instead of two reference
+                                   //   lanes per GPU lane (16 reads per wave)
+    IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels

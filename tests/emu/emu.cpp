@@ -266,7 +266,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     memset(ws.tb1.dir, 0x5A, (size_t)s1.dircap * ws.tb1_waves);
 
     if (n_jobs > 0) {
-        ipx_build_static_plans(be, b, ws);
+        ipx_build_static_plans(be, b, ws, d, routing);
         ipx_run_pipeline(be, b, ws, d, routing);
     }
 

@@ -215,7 +215,14 @@ def test_emu_bracket_certifies_or_steps(emu, oracle_mod, port):
     assert (res.records["mode"] == 0).all()                               # 8-bit semantics throughout
     assert _launched(a, K_BYTE_LOW) == [5] and _launched(a, K_BYTE_HIGH) == [5] and _launched(a, K_WORD_FIRST) == []
     # both stages in halves: the lower bound column by column (marker 3), the upper bound as a wavefront at segLen 2 x 5 (marker 2)
-    assert {k % 256 for k in a.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 3 + 5, 10 + 40 * 2 + 10}
+    # (marker 4: the lower bound with two reference lanes per GPU lane, 16 reads per wave; marker 2: the upper bound as a wavefront at 2 x 5 segments)
+    assert {k % 256 for k in a.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 4 + 5, 10 + 40 * 2 + 10}
+    # the same batch in the reference's 16-lane layout (8 reads per wave): same records
+    c = emu(0, 3, 2)
+    c.set_routing(R.ROUTE_NO_VL2)
+    res_c = c.align(jobs)
+    assert {k % 256 for k in c.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 3 + 5, 10 + 40 * 2 + 10}
+    assert all(res_c.as_dict(i) == res.as_dict(i) for i in range(jobs.n_jobs))
     n_low, n_high, n_exact = a.pass_jobs[1], a.pass_jobs[3], a.pass_jobs[4]
     assert n_low == 28 and n_high >= 20 and n_exact < n_high          # most of what reaches the upper-bound stage is certified
     b = emu(0, 3, 2)
