@@ -130,7 +130,8 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
  *   4 no upper-bound (bracket) stage         8 one traceback launch per band width
  *  16 column maxima in global scratch instead of LDS
  *  32 16-bit passes (and the 8-bit bracket stages) in packed integers even where packed halves are exact
- *  64 half-precision passes column by column with lazy-F instead of as a wavefront over the SSE lanes */
+ *  64 half-precision passes column by column with lazy-F instead of as a wavefront over the SSE lanes
+ * 128 8-bit lower-bound stage in the reference's 16-lane layout (8 reads per wave) instead of two lanes per GPU lane */
 int ipx_set_routing(ipx_ctx *c, int flags);
 
 /* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,
