@@ -44,9 +44,12 @@ def load(d, counter):
 
 def bench_name(k):
     """rocprof kernel symbol -> kernel class name of bench.py (ipx_kernel_class_name)"""
-    m = re.match(r"void k_dp_pass<(\d+), (\d+), (true|false), (true|false), (\d+)(?:, (?:true|false))*>", k)
+    m = re.match(r"void k_dp_pass<(\d+), (\d+), (true|false), (true|false), (\d+)((?:, (?:true|false))*)>", k)
     if m:
         w, s, rev, exact, stage = int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true", int(m.group(5))
+        flags = [x == "true" for x in re.findall(r"true|false", m.group(6))]        # selector profile, half precision, two lanes per GPU lane
+        if len(flags) >= 3 and flags[2]:                                           # the 8-bit lower-bound stage in the 8-lane layout
+            return "dp_byte_low_s%d" % (s // 2)
         if w == 16:
             base = "dp_byte_rev" if rev else ("dp_byte_exact", "dp_byte_low", "dp_byte_high")[stage]
         else:
