@@ -1232,8 +1232,11 @@ template <int W> IPX_DEV pk16 group_minu(pk16 x)
 //        finalisation speaks the 8-bit pass's dialect (end_ref starts at -1, the second-best scan reaches one column further,
 //        ssw.c:220, 374) and compares with the lower-bound stage's outputs in the record, as k_dp_pass HIGH does.  `cls` is the
 //        8-bit class the pass's job list is bucketed by; its tiles hold 16 jobs.
+// waves per SIMD to ask for: segLen 20..25 sits just above the three-wave register budget (170) -- a few spilled values cost less
+// than the third wave brings (r02: config 4's 200 bp class); longer reads run at two waves
+IPX_HD constexpr int ipx_skew_waves(int smax, bool rev) { return (smax >= 20 && smax <= 25) ? 3 : (rev ? ipx_dp_perm_waves(smax) : 1); }
 template <int SMAX, bool REV, bool BH = false>
-IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
+IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
 {
     static_assert(!(BH && REV), "the upper-bound stage is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
