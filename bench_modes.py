@@ -12,33 +12,34 @@ import time
 import numpy as np
 
 
-def run_end_to_end(ip, jobs, scoring, dev, streams, steps):
-    """A stream of job tables through ONE GPU, host memory to host memory.  Two aligners take the batches alternately:
-    while one computes, the other's results are downloaded and its next batch is cut, copied in and launched, so the
-    GPU never waits for the host or the PCIe link (each aligner: `streams` contexts, its own device buffers)."""
-    pair = [ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams) for _ in range(2)]
+def run_end_to_end(ip, jobs, scoring, dev, streams, steps, depth=None):
+    """A stream of job tables through ONE GPU, host memory to host memory.  `depth` aligners take the batches in turn: while
+    one computes, another's results are downloaded and a third's next batch is cut, copied in and launched, so the GPU does
+    not wait for the host or the PCIe link (each aligner: `streams` contexts, its own device buffers)."""
+    depth = depth or int(os.environ.get("IPX_E2E_DEPTH", "3"))
+    ring = [ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams) for _ in range(depth)]
     try:
-        pinned = all([g.pin_host(jobs) for g in pair])           # input arrays shared, one pinned output pair per aligner
-        for g in pair:                                           # warm-up: allocations, launch sizing
+        pinned = all([g.pin_host(jobs) for g in ring])           # input arrays shared, one pinned output pair per aligner
+        for g in ring:                                           # warm-up: allocations, launch sizing
             g.align(jobs)
         t0 = time.perf_counter()
-        pair[0].submit(jobs)
         res = None
-        for k in range(1, steps):
-            pair[k % 2].submit(jobs)                             # batch k is on its way ...
-            res = pair[(k - 1) % 2].collect()                    # ... while batch k-1 comes back
-        res = pair[(steps - 1) % 2].collect()
+        for k in range(steps + depth - 1):
+            if k < steps:
+                ring[k % depth].submit(jobs)                     # batch k is on its way ...
+            if k >= depth - 1:
+                res = ring[(k - depth + 1) % depth].collect()    # ... while batch k-depth+1 comes back
         dt = (time.perf_counter() - t0) / steps
         return {"value": round(jobs.n_jobs / dt / 1e6, 4), "unit": "million alignments/s", "ms_per_step": round(dt * 1e3, 3),
-                "steps": steps, "pinned_host_buffers": bool(pinned), "sum_score1": int(res.records["score1"].astype(np.int64).sum()),
-                "digest": res.digest(),
+                "steps": steps, "aligners_in_rotation": depth, "pinned_host_buffers": bool(pinned),
+                "sum_score1": int(res.records["score1"].astype(np.int64).sum()), "digest": res.digest(),
                 "bytes_in_per_step": int(jobs.reads.nbytes + jobs.read_off.nbytes + jobs.ref_id.nbytes + jobs.gap_open.nbytes
                                          + jobs.gap_ext.nbytes + jobs.refs.nbytes),
                 "bytes_out_per_step": int(res.records.nbytes + 4 * int(res.records["cigar_len"].astype(np.int64).sum())),
-                "note": "per batch: host job table -> H2D -> pipeline -> D2H of every record and CIGAR; two aligners alternate so "
-                        "that transfers and host work of one batch overlap the kernels of the other; never the headline value"}
+                "note": "per batch: host job table -> H2D -> pipeline -> D2H of every record and CIGAR; the aligners take batches "
+                        "in turn so that transfers and host work of one batch overlap the kernels of the others; never the headline value"}
     finally:
-        for g in pair:
+        for g in ring:
             g.close()
 
 
