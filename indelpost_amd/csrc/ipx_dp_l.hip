@@ -3,4 +3,3 @@
 #define IPX_DP_TEMPLATES_ONLY 1
 #include "ipx_kernels.h"
 IPX_DP_UNIT_L(IPX_SKEW_DEFINE)
-IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_DEFINE)

@@ -154,28 +154,38 @@ IPX_DEV int next_pass_key(const IpxBatch &b, const IpxResult &r, int readLen, bo
     case IPX_MODE_PENDING:
         if (b.score_size == 1) { pass = IPX_PASS_WORD_FWD; lanes = 8; }                      // 16-bit profile only (ssw.c:853-855)
         else if (b.score_size == 2 && b.word_first_len > 0 && readLen >= b.word_first_len) { pass = IPX_PASS_WORD_FIRST; lanes = 8; }
+        else if (b.plain_first) pass = slow ? IPX_PASS_BYTE_EXACT : IPX_PASS_BYTE_FIRST;     // plain recurrence first, certified afterwards (gap_open <= gap_ext: stepped at once)
         else if (readLen < b.byte_safe_len && (!b.use_bracket || readLen < b.bracket_min_len)) pass = IPX_PASS_BYTE_EXACT;
-        else pass = IPX_PASS_BYTE_LOW;                                                       // ssw.c:842-843
+        else pass = IPX_PASS_BYTE_FIRST;                                                     // ssw.c:842-843
         break;
     case IPX_MODE_NEED_BYTE_CHECK: pass = IPX_PASS_BYTE_CHECK; break;
     case IPX_MODE_NEED_BYTE_HIGH: pass = IPX_PASS_BYTE_HIGH; break;
+    case IPX_MODE_NEED_BYTE_LOW:
+    case IPX_MODE_NEED_BYTE_LOW_CMP: pass = IPX_PASS_BYTE_LOW2; break;
     case IPX_MODE_NEED_BYTE_EXACT:
     case IPX_MODE_NEED_BYTE_EXACT_W: pass = IPX_PASS_BYTE_EXACT; break;
     case IPX_MODE_NEED_WORD: pass = IPX_PASS_WORD_FWD; lanes = 8; break;                     // ssw.c:844-847
     case IPX_MODE_BYTE:
-        if (!rev_needed(b, r.score1)) return -1;
+        // (read_begin1 >= 0: a reverse pass has already located the begin position -- the plain reverse recurrence, certified)
+        if (!rev_needed(b, r.score1) || r.read_begin1 >= 0) return -1;
         pass = IPX_PASS_BYTE_REV; L = r.read_end1 + 1;                                       // ssw.c:875-886
+        break;
+    case IPX_MODE_BYTE_PLAIN:
+        if (!rev_needed(b, r.score1)) return -1;
+        pass = IPX_PASS_BYTE_REV_PLAIN; L = r.read_end1 + 1;
         break;
     case IPX_MODE_WORD:
         if (!rev_needed(b, r.score1)) return -1;
         pass = IPX_PASS_WORD_REV; L = r.read_end1 + 1; lanes = 8;
         break;
-    default: return -1;                                       // FAIL, WORD_UNPROVEN (k_prove_overflow moves those on)
+    default: return -1;                                       // FAIL; WORD_UNPROVEN, NEED_*_PROOF (the proof kernels move those on)
     }
     if (L < 0) L = 0;
-    const int cls = (L + lanes - 1) / lanes;
+    int cls = (L + lanes - 1) / lanes;
     if (cls > IPX_MAX_SEG) { atomic_or_u32(b.status, IPX_STATUS_READ_TOO_LONG); return -1; }
-    return pass * 256 + cls + (slow ? IPX_SLOW_BASE : 0);
+    if (slow) cls += IPX_SLOW_BASE;
+    if (b.cls_map) cls = b.cls_map[pass * IPX_NUM_CLASSES + cls];                            // (a rare class rides in a longer class's launch)
+    return pass * 256 + cls;
 }
 
 // class of job i in `pass`, or -1 when the job does not take part
@@ -1155,6 +1165,9 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
                     const bool has_word = r.mode == IPX_MODE_NEED_BYTE_CHECK || r.mode == IPX_MODE_NEED_BYTE_EXACT_W;
                     const int s2 = maskLen >= 15 ? (int)(F16 ? ipx_f16_to_uint(key2 >> 16) : (key2 >> 16)) : 0;  // ssw.c:864-870
                     const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
+                    // plain-first flow: this is the lower-bound stage AFTER the plain recurrence (IPX_PASS_BYTE_LOW2), whose outputs
+                    // the record may hold for comparison (proof failed) or not (the plain recurrence reached the overflow threshold)
+                    const bool cmp_plain = r.mode == IPX_MODE_NEED_BYTE_LOW_CMP, after_plain = cmp_plain || r.mode == IPX_MODE_NEED_BYTE_LOW;
                     if (HIGH) {
                         // the record holds the lower-bound stage's outputs: equal outputs certify them (see STAGE above);
                         // a read the upper-bound stage saw no big carry in is exact by itself
@@ -1169,6 +1182,17 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
                         if (has_word) r.mode = IPX_MODE_WORD;
                         else if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }            // -> 16-bit pass (ssw.c:844-847)
                         else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851
+                    } else if (after_plain) {
+                        const unsigned sc = F16 ? ipx_f16_to_uint(bh) : bh;
+                        const bool same = cmp_plain && r.score1 == (uint16_t)sc && r.ref_end1 == eref && r.read_end1 == end_read &&
+                                          r.score2 == (uint16_t)s2 && r.ref_end2 == e2;
+                        if (same) r.mode = rev_needed(b, sc) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE;   // squeezed between equal bounds: the reference's
+                        else if (lost) r.mode = IPX_MODE_NEED_BYTE_EXACT;                             // bounds differ: the stepped pass decides
+                        else {                                                                         // nothing was dropped: this IS the exact pass
+                            r.mode = IPX_MODE_BYTE;
+                            r.score1 = (uint16_t)sc; r.ref_end1 = eref; r.read_end1 = end_read; r.read_begin1 = -1;
+                            r.score2 = (uint16_t)s2; r.ref_end2 = e2;
+                        }
                     } else if (lost && (has_word || !b.use_bracket || L[h] < b.bracket_min_len)) {
                         r.mode = has_word ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_EXACT;             // lower bound only: exact 8-bit pass decides
                     } else {
@@ -1226,19 +1250,31 @@ template <int W> IPX_DEV pk16 group_minu(pk16 x)
     if (W == 16) x = pk_minu(x, xl_mirror(x));
     return x;
 }
-//   BH = the 8-bit forward pass's UPPER-BOUND stage (k_dp_pass HIGH) for reads of up to 8*SMAX bp: what that stage computes --
+//   BH = 1: the 8-bit forward pass's UPPER-BOUND stage (k_dp_pass HIGH) for reads of up to 8*SMAX bp: what that stage computes --
 //        every carry passed on -- is this same plain recurrence, whatever the striping (8 lanes here, 16 in the reference's 8-bit
 //        pass: row numbers, not lanes, enter the outputs), so it runs here at 16 reads per wave and without lazy-F.  The
 //        finalisation speaks the 8-bit pass's dialect (end_ref starts at -1, the second-best scan reaches one column further,
 //        ssw.c:220, 374) and compares with the lower-bound stage's outputs in the record, as k_dp_pass HIGH does.  `cls` is the
 //        8-bit class the pass's job list is bucketed by; its tiles hold 16 jobs.
+//   BH = 2: the same plain recurrence in the 8-bit dialect run FIRST (IPX_PASS_BYTE_FIRST of the plain-first flow, forward) and as the
+//        8-bit REVERSE pass of reads whose forward result equals the plain recurrence's (IPX_PASS_BYTE_REV_PLAIN).  The reference's
+//        8-bit matrix lies below the plain one cell by cell (its lazy-F loop only ever stops early, ssw.c:302-313) and equals it in
+//        every column processed before the first value >= 128 appears (no carry can reach the signed compare, ssw.c:311).  So:
+//        a best score < 128 is final as it stands; otherwise the outputs go into the record and k_prove_plain certifies them from
+//        below (a banded lower bound through the best cell) -- or hands the read to the lower-bound / stepped kernels.
+//   ROW SHIFT (r03): the kernel has 8*SMAX rows; a read whose padded row count in the reference (8*segLen, 16*segLen8 in the 8-bit
+//        dialect) is SMALLER is served all the same: its rows are shifted DOWN by the difference.  The rows above it select the
+//        constant score 0 and, starting from H = E = F = 0 with nothing but zeros arriving from above, stay 0 for ever -- they are
+//        the matrix's row -1 repeated -- so the read's own rows compute exactly what they would in a kernel of their own size, and
+//        the row numbers in the outputs are the kernel's minus the shift.  This lets the planner list a rare segLen class under the
+//        next populated one (IpxBatch::cls_map) instead of giving ~50 waves a launch to themselves on a 1 024-SIMD chip.
 // waves per SIMD to ask for: segLen 20..25 sits just above the three-wave register budget (170) -- a few spilled values cost less
 // than the third wave brings (r02: config 4's 200 bp class); longer reads run at two waves
 IPX_HD constexpr int ipx_skew_waves(int smax, bool rev) { return (smax >= 20 && smax <= 25) ? 3 : (rev ? ipx_dp_perm_waves(smax) : 1); }
-template <int SMAX, bool REV, bool BH = false>
+template <int SMAX, bool REV, int BH = 0>
 IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
 {
-    static_assert(!(BH && REV), "the upper-bound stage is a forward pass");
+    static_assert(!(BH == 1 && REV), "the upper-bound stage of the bracket is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
     constexpr int W = 8, G = 8, NA = 16, S = SMAX;
     const int lane = lane_id();
@@ -1298,8 +1334,13 @@ IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPla
                 }
             }
         }
+        // rows the read is shifted down by: the kernel's row count minus the reference's padded row count for this read (ROW SHIFT above)
+        int dl[2];
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) dl[h] = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
         {   // this kernel has no stepped lazy-F and computes in halves: refuse what would need more (host-side routing error)
-            const bool bad = (job[0] >= 0 && (gO[0] <= gE[0] || L[0] > b.f16_max_len)) || (job[1] >= 0 && (gO[1] <= gE[1] || L[1] > b.f16_max_len));
+            const bool bad = (job[0] >= 0 && (gO[0] <= gE[0] || L[0] > b.f16_max_len || dl[0] < 0)) ||
+                             (job[1] >= 0 && (gO[1] <= gE[1] || L[1] > b.f16_max_len || dl[1] < 0));
             if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
         }
         const pk16 go = pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1]));     // -gapO, -gapE as halves
@@ -1314,21 +1355,22 @@ IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPla
             for (int h = 0; h < 2; ++h) {
                 IPX_UNROLL
                 for (int j = 0; j < SMAX; ++j) {
-                    const int r = j + l * S;                       // striped row (ssw.c:178-185)
+                    const int r = j + l * S - dl[h];               // the read's row (ssw.c:178-185) held by this lane's segment j
                     int idx = r < L[h] ? r : L[h] - 1;
+                    if (idx < 0) idx = 0;
                     if (REV) idx = L[h] - 1 - idx;                 // reverse pass: seq_reverse (ssw.c:774-785)
                     raw[h][j] = load_stream_i8(L[h] > 0 ? rd[h] + idx : (const int8_t *)b.read_off);
                 }
             }
             IPX_UNROLL
             for (int j = 0; j < SMAX; ++j) {
-                const int r = j + l * S;
                 uint32_t sel = 0;
                 IPX_UNROLL
                 for (int h = 0; h < 2; ++h) {
+                    const int r = j + l * S - dl[h];
                     const unsigned base = (unsigned)raw[h][j];
-                    uint32_t sh = 0x0c0cu;                         // padding row / letter N: constant 0
-                    if (r < L[h] && base < 4u) sh = 0x000cu | ((base + 4u * h) << 8);   // high byte <- table byte 4*h + base
+                    uint32_t sh = 0x0c0cu;                         // rows above the read, padding rows, letter N: constant 0
+                    if (r >= 0 && r < L[h] && base < 4u) sh = 0x000cu | ((base + 4u * h) << 8);   // high byte <- table byte 4*h + base
                     sel |= sh << (16 * h);
                 }
                 SEL[j] = sel;
@@ -1475,16 +1517,20 @@ IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPla
         const pk16 isc = isb & ~pk_nzmask(lcol ^ cminA);                             // ... and the lanes that have it there
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
-            // end position on the read: smallest striped row holding `best` in that column (ssw.c:545-556)
+            // end position on the read: smallest striped row holding `best` in that column (ssw.c:545-556), counted from the read's
+            // first row (ROW SHIFT: the rows above it hold 0, which is the best only when nothing scored -- row 0 then, as in the reference)
             const unsigned bh = (bestA >> (16 * h)) & 0xFFFFu;
             const bool mine = ((isc >> (16 * h)) & 0xFFFFu) != 0;
+            const int shift = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
             uint32_t rmin = 0x7FFFFFFFu;
             IPX_UNROLL
             for (int j = SMAX - 1; j >= 0; --j)
                 if (mine && (((HM[j] >> (16 * h)) & 0xFFFFu) == bh)) rmin = (uint32_t)(j + l * S);
             rmin = group_umin<W>(rmin);
+            int rrow = (int)rmin - shift;
+            if (rrow < 0) rrow = 0;
             int end_read = L[h] - 1;
-            if ((int)rmin < end_read) end_read = (int)rmin;
+            if (rrow < end_read) end_read = rrow;
             const int cfirst = (int)((cminA >> (16 * h)) & 0xFFFFu);
             const int eref = bh == 0 ? (BH ? -1 : 0) : (REV ? idx0[h] - cfirst : cfirst);   // (never improved: the initial 0 / -1, ssw.c:427 / 220)
             const unsigned bv = ipx_f16_to_uint(bh);
@@ -1498,20 +1544,23 @@ IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPla
                 int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
                 if (BH) edgeR += 1;                                   // ssw.c:374
                 uint32_t key2 = 0xFFFFu;                              // (score2 = 0, ref_end2 = 0)
+                uint32_t cbig = 0x7FFFFFFFu;                          // (BH = 2) first column holding a value >= 128
                 for (int col = l; col < refLen; col += W) {
+                    const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
+                    if (BH == 2 && v >= 0x5800u && cbig == 0x7FFFFFFFu) cbig = (uint32_t)col;      // (0x5800 = 128.0; non-negative halves order like integers)
                     if (col < edgeL || col >= edgeR) {
-                        const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
                         const uint32_t kk = (v << 16) | (0xFFFFu - (uint32_t)col);
                         if (v > (key2 >> 16)) key2 = kk;
                     }
                 }
                 key2 = group_umax<W>(key2);
+                if (BH == 2) cbig = group_umin<W>(cbig);
                 int key = -1;                                         // pass the job takes next (plan_note below)
                 if (l == 0 && job[h] >= 0) {
                     IpxResult r = b.res[job[h]];
                     const uint16_t s2 = (uint16_t)(maskLen >= 15 ? ipx_f16_to_uint(key2 >> 16) : 0u);         // ssw.c:864-870
                     const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
-                    if (BH) {
+                    if (BH == 1) {
                         // the record holds the lower-bound stage's outputs: equal outputs certify them (k_dp_pass STAGE); an upper
                         // bound that reaches the overflow threshold certifies nothing
                         const bool same = bv < (unsigned)(255 - b.bias) && r.score1 == (uint16_t)bv && r.ref_end1 == eref && r.read_end1 == end_read &&
@@ -1519,13 +1568,21 @@ IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPla
                         r.mode = same ? IPX_MODE_BYTE : IPX_MODE_NEED_BYTE_EXACT;
                         if (same) r.read_begin1 = -1;
                     } else {
-                        r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
                         r.score1 = (uint16_t)bv;
                         r.ref_end1 = eref;
                         r.read_end1 = end_read;
                         r.read_begin1 = -1;
                         r.score2 = s2;
                         r.ref_end2 = e2;
+                        if (BH == 2) {
+                            // plain recurrence first (see BH = 2 above): below 128 nothing can reach the signed compare and the
+                            // result is the reference's; at the overflow threshold it says nothing; in between it is the candidate
+                            // k_prove_plain certifies -- the second-best column needs no proof when it was processed before any
+                            // value >= 128 existed (or is the initial 0)
+                            if (bv >= (unsigned)(255 - b.bias)) r.mode = IPX_MODE_NEED_BYTE_LOW;
+                            else if (bv < 128u) r.mode = rev_needed(b, bv) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE;
+                            else r.mode = (s2 == 0 || (e2 >= 0 && (uint32_t)e2 < cbig)) ? IPX_MODE_NEED_FWD_PROOF : IPX_MODE_NEED_FWD_PROOF2;
+                        } else r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
                     }
                     b.res[job[h]] = r;
                     key = next_pass_key(b, r, L[h], false);
@@ -1537,6 +1594,8 @@ IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPla
                     r.ref_begin1 = eref;                                                                       // ssw.c:885
                     r.read_begin1 = rend1[h] - end_read;                                                       // ssw.c:886
                     if ((unsigned)score1[h] > bv) r.flag = 2;                                                  // ssw.c:888-891
+                    // (BH = 2) the plain reverse recurrence: final below 128, otherwise k_prove_plain certifies the begin cell
+                    if (BH == 2) r.mode = score1[h] < 128 ? IPX_MODE_BYTE : IPX_MODE_NEED_REV_PROOF;
                     b.res[job[h]] = r;
                 }
             }
@@ -1709,6 +1768,198 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
             }
             plan_note(b, key);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prove_plain<REV>: certify, from BELOW, an output of the plain recurrence that k_dp_skew (BH = 2) has put into the record.
+//
+// The reference's 8-bit matrix H8 (sw_sse2_byte, ssw.c:197-384) lies below the plain recurrence's matrix cell by cell, because
+// its lazy-F loop can only stop early (ssw.c:311).  It lies ABOVE every score that is reachable with moves the main loop
+// (ssw.c:274-299) and the first, unconditional step of the lazy-F loop (k = 0, j = 0, ssw.c:303-308: applied before any exit
+// test) are certain to make -- the "safe moves":
+//   diagonal steps (the diagonal is read from the final column, pvHStore);
+//   horizontal gaps (E is fed by the main loop's H, ssw.c:286-291);
+//   vertical gaps INSIDE a segment of the striped layout (F of the main loop, ssw.c:294-296);
+//   a vertical gap step INTO the first row of a segment (row % segLen8 == 0) from the row above: that is lazy-F's first step.
+//     The value it leaves there is a FINAL H only: the next column's diagonal sees it, this row's E and the F chain below it
+//     do not (lazy-F corrects neither, ssw.c:302).
+// (Checked cell by cell against the reference's loop on 30 000 adversarial inputs, 9 x 10^8 cells, before it went in; the
+// stress tests pin the whole route.)  So if the safe-move score of the cell the plain recurrence names equals the plain value,
+// H8 has that value there too, and -- H8 being nowhere larger than the plain matrix -- the output built on that cell is the
+// reference's: the best score, its first column and smallest row (forward), the begin cell (reverse).  The second-best column
+// (forward, NEED_FWD_PROOF2: a column at or after the first value >= 128) is certified the same way from a witness in that
+// column: a band cell, or the horizontal gap that leaves the band towards it -- typically the tail of the best cell carried
+// through the padding rows.  One lane per read: the ungapped diagonal first (exact for every read without an indel), then a
+// band of IPX_PROVE_BAND diagonals around the target's diagonal for the reads still open, queued so that waves stay full.
+// A read whose proof fails takes the lower-bound stage (forward: IPX_PASS_BYTE_LOW2, compared with the record) or the stepped
+// reverse pass (IPX_PASS_BYTE_REV).
+// ------------------------------------------------------------------------------------------------
+struct IpxProveTarget {
+    int Lp, ncols;            // rows (letters of the pass's read) and columns (of its window) of the pass
+    int r1, c1, v1;           // the cell to certify and the value it must reach
+    int e2, s2;               // second-best column and its value; e2 < 0: nothing to certify there
+};
+// letter of row rr / column c in PASS coordinates (reverse pass: reversed read prefix, window walked right to left)
+template <bool REV> IPX_DEV int prove_read_letter(const int8_t *rd, int Lp, int rr) { int a = rd[REV ? Lp - 1 - rr : rr]; return (unsigned)a > 4u ? 4 : a; }
+template <bool REV> IPX_DEV unsigned prove_ref_letter(const int8_t *rf, int ncols, int c)
+{
+    return (c >= 0 && c < ncols) ? (unsigned)(uint8_t)rf[REV ? ncols - 1 - c : c] : 7u;
+}
+
+// ungapped: the target's diagonal alone, and the second-best witness through the padding rows and one horizontal gap
+template <bool REV>
+IPX_DEV bool prove_plain_ungapped(const IpxBatch &b, const IpxProveTarget &t, const int8_t *rd, const int8_t *rf, int go, int ge)
+{
+    const int m = t.r1 < t.c1 ? t.r1 : t.c1;
+    int u = 0;
+    for (int k = m; k >= 0; --k) {
+        const int a = prove_read_letter<REV>(rd, t.Lp, t.r1 - k);
+        const unsigned c = prove_ref_letter<REV>(rf, t.ncols, t.c1 - k);
+        u += b.mat[c * 5 + a];
+        if (u < 0) u = 0;
+    }
+    if (u < t.v1) return false;
+    if (t.e2 < 0) return true;
+    // rows r1+1 .. rows-1 carry the value down the diagonal (padding rows score 0, ssw.c:174-176); only past the read's last letter
+    const int rows = 16 * ((t.Lp + 15) >> 4);
+    int pad = t.r1 == t.Lp - 1 ? rows - 1 - t.r1 : 0;
+    if (t.c1 + pad > t.ncols - 1) pad = t.ncols - 1 - t.c1;
+    const int cs = t.c1 + pad;
+    return t.e2 > cs && u - go - (t.e2 - cs - 1) * ge >= t.s2;
+}
+
+template <bool REV>
+IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const int8_t *rd, const int8_t *rf, int go, int ge, const uint64_t *coltab)
+{
+    constexpr int BW = IPX_PROVE_BAND, HB = BW / 2;
+    const int S8 = (t.Lp + 15) >> 4;                       // segLen of the 8-bit pass (ssw.c:221)
+    const int rows = 16 * S8;
+    const int d0 = t.c1 - t.r1;
+    const int last = t.e2 >= 0 ? rows - 1 : t.r1;          // the second-best witness may sit in the padding rows
+    int Hm[BW], Hf[BW], F[BW];                             // previous row: main-loop H, final H, F entering the row; cell k = column row + d0 - HB + k
+    IPX_UNROLL
+    for (int k = 0; k < BW; ++k) { Hm[k] = 0; Hf[k] = 0; F[k] = 0; }
+    uint64_t win = 0;                                      // 4 bits per band cell: window letter, 7 = outside the window
+    IPX_UNROLL
+    for (int k = 0; k < BW; ++k) win |= (uint64_t)prove_ref_letter<REV>(rf, t.ncols, d0 - HB + k) << (4 * k);
+    int seg = 0, got = -1, w2 = -1, wb = -(1 << 28);
+    int a_next = t.Lp > 0 ? prove_read_letter<REV>(rd, t.Lp, 0) : 4;
+    for (int rr = 0; rr <= last; ++rr) {
+        const int a = a_next;
+        a_next = rr + 1 < t.Lp ? prove_read_letter<REV>(rd, t.Lp, rr + 1) : 4;
+        const uint64_t row = rr < t.Lp ? coltab[a] : 0ull;  // padding rows score 0 against every letter
+        const bool cross = seg == 0;
+        int e = 0, hleft = 0;
+        IPX_UNROLL
+        for (int k = 0; k < BW; ++k) {
+            const unsigned cl = (unsigned)(win >> (4 * k)) & 7u;
+            const int c = rr + d0 - HB + k;
+            int f = 0;                                     // F entering this row in column c: from the cell above = cell k+1 of the previous row
+            if (k + 1 < BW) {
+                const int f1 = F[k + 1] - ge, f2 = Hm[k + 1] - go;
+                f = f1 > f2 ? f1 : f2;
+                if (f < 0) f = 0;
+            }
+            {
+                const int e1 = e - ge, e2 = hleft - go;
+                e = e1 > e2 ? e1 : e2;
+                if (e < 0) e = 0;
+            }
+            int hm = Hf[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
+            if (hm < e) hm = e;
+            if (hm < 0) hm = 0;
+            int hf, fk;
+            if (!cross) { if (hm < f) hm = f; hf = hm; fk = f; }      // inside a segment: the main loop's own F
+            else { hf = hm > f ? hm : f; fk = 0; }                   // first row of a segment: lazy-F's first step, a final value only
+            if (cl > 4u) { hm = 0; hf = 0; e = 0; fk = 0; }          // outside the window
+            Hm[k] = hm; Hf[k] = hf; F[k] = fk; hleft = hm;
+            if (t.e2 >= 0 && cl <= 4u) {
+                if (c == t.e2 && hf > w2) w2 = hf;
+                if (c < t.e2 && hm + c * ge > wb) wb = hm + c * ge;
+            }
+        }
+        if (rr == t.r1) got = Hf[HB];
+        win = (win >> 4) | ((uint64_t)prove_ref_letter<REV>(rf, t.ncols, rr + 1 + d0 + HB) << (4 * (BW - 1)));
+        if (++seg == S8) seg = 0;
+    }
+    if (got < t.v1) return false;
+    if (t.e2 < 0) return true;
+    if (wb - go - (t.e2 - 1) * ge > w2) w2 = wb - go - (t.e2 - 1) * ge;
+    return w2 >= t.s2;
+}
+
+template <bool REV>
+IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
+{
+    const int lane = lane_id();
+    uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
+    uint32_t *queue = (uint32_t *)(IPX_LDS_BASE + 64);             // jobs (index inside the chunk) waiting for the band
+    if (lane < 5) {
+        uint64_t tt = 0;
+        for (int c = 0; c < 5; ++c) tt |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
+        coltab[lane] = tt;
+    }
+    IPX_SYNC();
+    const int64_t nb = (b.n_jobs + 63) / 64;
+    const int CB = chunk_blocks < 1 ? 1 : chunk_blocks > IPX_PROVE_CHUNK ? IPX_PROVE_CHUNK : chunk_blocks;
+    const int64_t nchunk = (nb + CB - 1) / CB;
+    for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
+        const int64_t cbase = chunk * CB * 64;
+        uint32_t qn = 0;                                           // queued jobs (the same in every lane)
+        for (int round = 0; round < 2; ++round) {
+            // round 0: every job of the chunk, ungapped test, the rest queued; round 1: the queue, band
+            const uint32_t total = round == 0 ? (uint32_t)(CB * 64) : qn;
+            if (round == 1) IPX_SYNC();                            // queue entries written
+            for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+                int64_t i = -1;
+                if (round == 0) { const int64_t ii = cbase + q0 + lane; if (ii < b.n_jobs) i = ii; }
+                else if (q0 + (uint32_t)lane < qn) i = cbase + (int64_t)queue[q0 + lane];
+                int key = -1;
+                bool open = false;
+                if (i >= 0) {
+                    IpxResult r = b.res[i];
+                    const bool mine = REV ? r.mode == IPX_MODE_NEED_REV_PROOF : (r.mode == IPX_MODE_NEED_FWD_PROOF || r.mode == IPX_MODE_NEED_FWD_PROOF2);
+                    if (mine) {
+                        const int rid = b.ref_id[i];
+                        const int8_t *rd = b.reads + b.read_off[i];
+                        const int8_t *rf = b.refs_packed + b.refp_off[rid];
+                        const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+                        IpxProveTarget t;
+                        if (!REV) {
+                            t.Lp = Lr; t.ncols = b.ref_len[rid]; t.r1 = r.read_end1; t.c1 = r.ref_end1; t.v1 = r.score1;
+                            t.e2 = r.mode == IPX_MODE_NEED_FWD_PROOF2 ? r.ref_end2 : -1; t.s2 = r.score2;
+                        } else {
+                            t.Lp = r.read_end1 + 1; t.ncols = r.ref_end1 + 1; t.r1 = r.read_end1 - r.read_begin1; t.c1 = r.ref_end1 - r.ref_begin1;
+                            t.v1 = r.score1; t.e2 = -1; t.s2 = 0;
+                        }
+                        const bool sane = t.r1 >= 0 && t.r1 < t.Lp && t.c1 >= 0 && t.c1 < t.ncols;
+                        bool ok = false, decided = true;
+                        if (sane) {
+                            if (round == 0) { ok = prove_plain_ungapped<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i]); decided = ok; }
+                            else ok = prove_plain_band<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab);
+                        }
+                        if (!decided) open = true;
+                        else {
+                            if (!REV) r.mode = ok ? (rev_needed(b, r.score1) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE) : IPX_MODE_NEED_BYTE_LOW_CMP;
+                            else {
+                                r.mode = IPX_MODE_BYTE;                      // certified: final; otherwise the stepped reverse pass decides
+                                if (!ok) { r.ref_begin1 = -1; r.read_begin1 = -1; }
+                            }
+                            b.res[i] = r;
+                            key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
+                        }
+                    }
+                }
+                plan_note(b, key);
+                if (round == 0) {
+                    const uint64_t om = xl_ballot(open);
+                    if (open) queue[qn + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
+                    qn += (uint32_t)__builtin_popcountll(om);
+                }
+            }
+        }
+        IPX_SYNC();                                                // the queue is free for the next chunk
     }
 }
 
@@ -2273,16 +2524,19 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
     X(0, REV) X(1, REV) X(2, REV) X(3, REV) X(4, REV) X(5, REV) X(6, REV) X(7, REV) X(8, REV) X(9, REV) X(10, REV) X(11, REV)    \
     X(12, REV) X(13, REV) X(14, REV) X(15, REV) X(16, REV) X(17, REV) X(18, REV) X(19, REV) X(20, REV) X(21, REV) X(22, REV)     \
     X(23, REV) X(24, REV) X(25, REV) X(26, REV) X(27, REV) X(28, REV) X(29, REV) X(30, REV) X(31, REV) X(32, REV)
-#define IPX_SKEW_DEFINE(S, REV) template __global__ void k_dp_skew<S, REV>(IpxBatch, IpxPlan, int, int, int);
-#define IPX_SKEW_EXTERN(S, REV) extern template __global__ void k_dp_skew<S, REV>(IpxBatch, IpxPlan, int, int, int);
-#define IPX_SKEW_BH_FAMILY(X)                                                                                                \
-    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
-#define IPX_SKEW_BH_DEFINE(S) template __global__ void k_dp_skew<S, false, true>(IpxBatch, IpxPlan, int, int, int);
-#define IPX_SKEW_BH_EXTERN(S) extern template __global__ void k_dp_skew<S, false, true>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_SKEW_DEFINE(S, REV) template __global__ void k_dp_skew<S, REV, 0>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_SKEW_EXTERN(S, REV) extern template __global__ void k_dp_skew<S, REV, 0>(IpxBatch, IpxPlan, int, int, int);
+// the plain recurrence in the 8-bit dialect: 8-bit classes 1..16 = 2, 4, .., 32 segments of the 8-lane layout
+#define IPX_SKEW_BH_FAMILY(X, REV, BH)                                                                                       \
+    X(2, REV, BH) X(4, REV, BH) X(6, REV, BH) X(8, REV, BH) X(10, REV, BH) X(12, REV, BH) X(14, REV, BH) X(16, REV, BH)         \
+    X(18, REV, BH) X(20, REV, BH) X(22, REV, BH) X(24, REV, BH) X(26, REV, BH) X(28, REV, BH) X(30, REV, BH) X(32, REV, BH)
+#define IPX_SKEW_BH_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_SKEW_BH_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 #if defined(IPX_EXTERN_KERNELS)
-IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN)
+IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
+IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 1) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 2) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, true, 2)
 IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H) IPX_DP_UNIT_M(IPX_DP_EXTERN_H) IPX_VL2_FAMILY(IPX_VL2_EXTERN)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)

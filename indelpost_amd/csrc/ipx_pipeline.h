@@ -2,8 +2,10 @@
 // ssw.c:842-916, over a whole job table).  Written against a tiny launcher so the HIP runtime
 // (ipx_runtime.hip) and the test-only wave emulator (tests/emu) run the identical sequence.
 //
-//   init -> [16-bit forward first + overflow proof, long reads] -> [8-bit forward: lower bound, upper bound, stepped]
-//        -> [16-bit forward for overflowed reads] -> [8-bit reverse] -> [16-bit reverse] -> traceback list -> banded traceback
+//   init -> [16-bit forward first + overflow proof, long reads]
+//        -> [8-bit forward: plain recurrence + proof, else lower bound, else stepped   (r02 order: lower bound, upper bound, stepped)]
+//        -> [16-bit forward for overflowed reads] -> [8-bit reverse: plain recurrence + proof, else stepped] -> [16-bit reverse]
+//        -> traceback list -> banded traceback
 //
 // No host synchronisation happens between the stages: which job takes which branch is decided on the device.  The
 // job lists of the two passes every job STARTS in depend only on host-known facts and are built once per resident
@@ -40,7 +42,14 @@ struct IpxDims {
     // derived by ipx_dims_finish for the current scoring parameters: classes (segLen, + IPX_SLOW_BASE when slow) present
     uint8_t has8_low[IPX_NUM_CLASSES], has8_wf[IPX_NUM_CLASSES];     // 8-bit classes of the reads that start in the 8-bit / in the 16-bit-first pass
     uint8_t has16_low[IPX_NUM_CLASSES], has16_wf[IPX_NUM_CLASSES];   // 16-bit classes of the same two sets
-    uint8_t any_wf, any_low;           // some read starts in the 16-bit-first pass / in the 8-bit lower-bound stage
+    uint8_t any_wf, any_low;           // some read starts in the 16-bit-first pass / in the first 8-bit stage
+    // derived by ipx_plan_classes: where the wavefront kernels (k_dp_skew) serve a pass, the class every class is LISTED under
+    // (IpxBatch::cls_map) and the classes that get a launch
+    uint8_t cls_map[IPX_NUM_PASSES][IPX_NUM_CLASSES];
+    uint8_t set[IPX_NUM_PASSES][IPX_NUM_CLASSES];
+    uint8_t word_sets;                 // the fast-gap classes of the three 16-bit passes are launched from `set` (wavefront kernels throughout)
+    uint8_t plain_first;               // the 8-bit passes take the plain-first flow (IpxBatch::plain_first)
+    uint8_t high_sets;                 // (bracket flow) the upper-bound stage runs as a wavefront, launched from `set`
 };
 
 static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
@@ -54,9 +63,10 @@ static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
 // kernel classes for per-kernel timing (ipx_runtime.hip records HIP events around each launch)
 enum {
     IPX_K_INIT = 0, IPX_K_PLAN, IPX_K_BYTE_LOW, IPX_K_BYTE_CHECK, IPX_K_BYTE_HIGH, IPX_K_BYTE_EXACT, IPX_K_WORD_FIRST, IPX_K_WORD_FWD,
-    IPX_K_BYTE_REV, IPX_K_WORD_REV, IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_PROVE, IPX_K_NUM
+    IPX_K_BYTE_REV, IPX_K_WORD_REV, IPX_K_TB_LIST, IPX_K_TRACEBACK, IPX_K_PACK, IPX_K_PROVE,
+    IPX_K_BYTE_PLAIN, IPX_K_BYTE_LOW2, IPX_K_BYTE_REV_PLAIN, IPX_K_PROVE_PLAIN, IPX_K_NUM
 };
-static inline bool ipx_k_is_dp(int kc) { return kc >= IPX_K_BYTE_LOW && kc <= IPX_K_WORD_REV; }
+static inline bool ipx_k_is_dp(int kc) { return (kc >= IPX_K_BYTE_LOW && kc <= IPX_K_WORD_REV) || (kc >= IPX_K_BYTE_PLAIN && kc <= IPX_K_BYTE_REV_PLAIN); }
 
 // DP grid cap, in blocks (= waves) per CU.  Far more than are resident (<= 24): with several streams
 // sharing the GPU, short-lived blocks let the kernels of different streams interleave and even out the
@@ -173,13 +183,15 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 // Reverse passes align a read PREFIX whose length is only known on the device: almost always the
 // prefix has the read's own class or the one below, so those get their exact-segLen launch and ONE
 // branch-guarded launch sweeps up every other class (it skips the tiles the exact launches own).
+// halves: bit 0 = the fast-gap classes, bit 1 = the slow-gap classes (gap_open <= gap_ext) of `has` are served here
 template <class BE, int W, bool REV, int STAGE>
-static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass, int routing)
+static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass, int routing, int halves = 3)
 {
     uint64_t exact[2] = {0, 0};                                   // classes with their own launch: [0] fast, [1] slow gaps
     bool rest = false;                                            // anything the exact launches do not cover?
     int need = 0;                                                 // ... and its largest segLen
     for (int half = 0; half < 2; ++half) {
+        if (!((halves >> half) & 1)) { exact[half] = ~0ull; continue; }       // (not ours: the sweep below skips these tiles too)
         const uint8_t *hs = has + half * IPX_SLOW_BASE;
         int top = -1;
         for (int c = 0; c <= IPX_MAX_SEG; ++c) if (hs[c]) top = c;
@@ -212,6 +224,36 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uin
               ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols, false, routing), b, p, 0, last, maxcols, pass, exact[0], exact[1]);
 }
 
+// Wavefront launches of a pass whose (fast-gap) classes were planned by ipx_plan_classes: one k_dp_skew launch per class of `set`.
+// BH = 0: 16-bit passes, class c = c segments.  BH = 1 / 2: the plain recurrence in the 8-bit dialect, class c (8-bit segLen) = 2c
+// segments of the 8-lane layout.  A launch also serves the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).
+template <class BE, bool REV, int BH>
+static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing)
+{
+    const int lds = ipx_dp_lds_bytes(8, 0, REV, maxcols, true, routing);
+    const int pflag = pass | (ipx_dp_mc_in_lds(8, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
+    for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
+        if (!set[c]) continue;
+        be.note_dp(IPX_KEY(kclass, c), pass, c, 16);
+        be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
+#define IPX_SK_CASE(C)                                                                                                         \
+    case C:                                                                                                                    \
+        if constexpr (BH != 0) {                                                                                               \
+            if constexpr ((C) >= 1 && (C) <= 16)                                                                               \
+                be.launch(IPX_KEY(kclass, c), k_dp_skew<2 * (C), REV, BH>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); \
+        } else be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), REV, 0>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag);     \
+        break;
+        switch (c) {
+            IPX_SK_CASE(0) IPX_SK_CASE(1) IPX_SK_CASE(2) IPX_SK_CASE(3) IPX_SK_CASE(4) IPX_SK_CASE(5) IPX_SK_CASE(6) IPX_SK_CASE(7) IPX_SK_CASE(8)
+            IPX_SK_CASE(9) IPX_SK_CASE(10) IPX_SK_CASE(11) IPX_SK_CASE(12) IPX_SK_CASE(13) IPX_SK_CASE(14) IPX_SK_CASE(15) IPX_SK_CASE(16)
+            IPX_SK_CASE(17) IPX_SK_CASE(18) IPX_SK_CASE(19) IPX_SK_CASE(20) IPX_SK_CASE(21) IPX_SK_CASE(22) IPX_SK_CASE(23) IPX_SK_CASE(24)
+            IPX_SK_CASE(25) IPX_SK_CASE(26) IPX_SK_CASE(27) IPX_SK_CASE(28) IPX_SK_CASE(29) IPX_SK_CASE(30) IPX_SK_CASE(31) IPX_SK_CASE(32)
+        default: break;
+        }
+#undef IPX_SK_CASE
+    }
+}
+
 // one scatter launch turns the counts of a pass (left by the kernels that sent jobs into it) into its job list;
 // count_first: the jobs come straight from their initial state, count them here
 template <class BE>
@@ -225,17 +267,19 @@ static void ipx_plan_pass(BE &be, const IpxBatch &b, const IpxPlan &p, int pass,
 static inline uint32_t *ipx_plan_count_of(uint32_t *tables, int pass) { return tables + (size_t)pass * 2 * IPX_NUM_CLASSES; }
 #define IPX_PLAN_TABLE_WORDS (IPX_NUM_PASSES * 2 * IPX_NUM_CLASSES)
 
+// tile size (alignments per wave) of the first 8-bit stage
+static inline int ipx_first_na(const IpxBatch &b, const IpxDims &d, int routing) { return (d.plain_first || ipx_low2_ok(b, d, routing)) ? 16 : 8; }
+
 // The job lists of the passes a job starts in (every record PENDING): they depend on the read lengths, the penalties
 // and the scoring parameters only, so they are built when a batch (or the parameters) changed, not in every run.
 template <class BE>
 static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing)
 {
-    const int na_low = ipx_low2_ok(b, d, routing) ? 16 : 8;      // tile size of the lower-bound stage (ipx_run_pipeline uses the same rule)
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, 0), IPX_FIRST_DYNAMIC_PASS * 2 * IPX_NUM_CLASSES);
     if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, 16, true);
     if (b.score_size != 1) {
-        ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW], IPX_PASS_BYTE_LOW, na_low, true);
+        ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_FIRST], IPX_PASS_BYTE_FIRST, ipx_first_na(b, d, routing), true);
         // jobs that start in the stepped pass: counted now, their count seeds that pass's (dynamic) row in every run
         be.zero_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, IPX_NUM_CLASSES);
         be.launch(IPX_KEY(IPX_K_PLAN, 0), k_plan_count, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, (int)IPX_PASS_BYTE_EXACT);
@@ -258,17 +302,35 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     const bool low2 = ipx_low2_ok(b, d, routing);                 // 8-bit lower-bound launches: 16 reads per wave (k_dp_pass VL2)
     if (low2) routing |= IPX_ROUTE_INTERNAL_VL2;
     const bool wf = b.score_size == 2 && d.any_wf;
+    // the fast-gap classes of a 16-bit pass: from the planned set as wavefronts, or class by class (ipx_launch_dp); slow-gap classes always the latter
+    const int word_halves = d.word_sets ? 2 : 3;
+    const int prove_chunk = b.n_jobs >= IPX_PROVE_CHUNK_MIN_JOBS ? IPX_PROVE_CHUNK : 1;   // (small batches: shortest chain of rounds per wave)
     if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
-        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
+        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
+        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, word_halves);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
-        const int chunk_blocks = b.n_jobs >= IPX_PROVE_CHUNK_MIN_JOBS ? IPX_PROVE_CHUNK : 1;   // (small batches: shortest chain of rounds per wave)
-        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(cap), b, cap, chunk_blocks);
+        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(cap), b, cap, prove_chunk);
     }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
+        if (d.plain_first) {
+            // plain recurrence first (k_dp_skew BH = 2), certified from below by k_prove_plain; what neither settles takes the
+            // lower-bound stage (compared with the plain outputs) and, failing that, the stepped pass.  (Jobs with gap_open <= gap_ext
+            // start in the stepped pass: next_pass_key.)
+            if (d.any_low) {
+                ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing);
+                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, be.flat_grid(b.n_jobs * 4), 64, 64 + 256 * IPX_PROVE_CHUNK, b, prove_chunk);
+                ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
+                ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1);
+            }
+            if (wf) {                                            // word-first reads whose overflow could not be proven
+                ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
+                ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
+            }
+        } else {
         if (d.any_low)
-            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW], d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_LOW, routing);
+            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_FIRST, routing);
         if (wf) {                                                // word-first reads whose overflow could not be proven
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
@@ -279,50 +341,36 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             memcpy(hs, d.has8_low, IPX_SLOW_BASE);
             // "every carry passed on" is the plain recurrence: where halves are exact for these reads it runs as a wavefront at 16
             // reads per wave (k_dp_skew BH, read lengths up to 256); otherwise column by column in the 8-bit layout
-            int top8 = 0;
-            for (int c = 0; c < IPX_SLOW_BASE; ++c) if (hs[c]) top8 = c;
-            const bool wave_high = ipx_perm_profile_ok(b.mat, routing) && !(routing & (IPX_ROUTE_NO_F16 | IPX_ROUTE_NO_SKEW)) &&
-                                   top8 >= 1 && top8 <= 16 && 16 * top8 <= b.f16_max_len;
-            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_HIGH], IPX_PASS_BYTE_HIGH, wave_high ? 16 : 8);
-            if (wave_high) {
-                const IpxPlan &ph = ws.plan[IPX_PASS_BYTE_HIGH];
-                for (int c = 1; c <= top8; ++c) {
-                    if (!hs[c]) continue;
-                    be.note_dp(IPX_KEY(IPX_K_BYTE_HIGH, c), IPX_PASS_BYTE_HIGH, c, 16);
-                    be.note_f16(2, 2 * c);
-#define IPX_BH_CASE(C)                                                                                                    \
-    case C:                                                                                                               \
-        be.launch(IPX_KEY(IPX_K_BYTE_HIGH, c), k_dp_skew<2 * C, false, true>, be.dp_grid(IPX_PASS_BYTE_HIGH, c), 64,      \
-                  ipx_dp_lds_bytes(8, 2 * C, false, maxcols, true, routing), b, ph, c, maxcols,                           \
-                  IPX_PASS_BYTE_HIGH | (ipx_dp_mc_in_lds(8, false, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0));       \
-        break;
-                    switch (c) {
-                        IPX_BH_CASE(1) IPX_BH_CASE(2) IPX_BH_CASE(3) IPX_BH_CASE(4) IPX_BH_CASE(5) IPX_BH_CASE(6) IPX_BH_CASE(7) IPX_BH_CASE(8)
-                        IPX_BH_CASE(9) IPX_BH_CASE(10) IPX_BH_CASE(11) IPX_BH_CASE(12) IPX_BH_CASE(13) IPX_BH_CASE(14) IPX_BH_CASE(15) IPX_BH_CASE(16)
-                    default: break;
-                    }
-#undef IPX_BH_CASE
-                }
-            } else
-            ipx_launch_dp<BE, 16, false, IPX_STAGE_HIGH>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], hs, maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_HIGH], IPX_PASS_BYTE_HIGH, d.high_sets ? 16 : 8);
+            if (d.high_sets) ipx_launch_skew_set<BE, false, 1>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], d.set[IPX_PASS_BYTE_HIGH], maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
+            else ipx_launch_dp<BE, 16, false, IPX_STAGE_HIGH>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], hs, maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
         }
-        // reads the bracket left open: the reference's stepped lazy-F
+        }
+        // reads the bounds left open: the reference's stepped lazy-F
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_EXACT], IPX_PASS_BYTE_EXACT, 8);
         ipx_launch_dp<BE, 16, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_EXACT], has8_all, maxcols, IPX_K_BYTE_EXACT, IPX_PASS_BYTE_EXACT, routing);
     }
     if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, 16, b.score_size == 1);
+        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], b.score_size == 1 ? has16_all : d.has16_low, maxcols,
-                                                     IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing);
+                                                     IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, word_halves);
     }
     if (b.flag != 0) {                                           // begin position (ssw.c:872-886)
         if (b.score_size != 1) {
+            if (d.plain_first) {
+                // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
+                ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, 16);
+                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing);
+                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, be.flat_grid(b.n_jobs * 4), 64, 64 + 256 * IPX_PROVE_CHUNK, b, prove_chunk);
+            }
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
             ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing);
         }
         if (b.score_size != 0) {
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, 16);
-            ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing);
+            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing);
+            ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, word_halves);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
@@ -438,6 +486,80 @@ static inline void ipx_dims_finish(IpxDims &d, int word_first_len, int score_siz
             (wfirst ? d.has16_wf : d.has16_low)[c16 + slow * IPX_SLOW_BASE] = 1;
             if (wfirst) d.any_wf = 1; else if (len >= exact_start_len) d.any_low = 1;   // (shorter ones start in the stepped pass)
         }
+}
+
+// Where the wavefront kernels serve a pass: which class every class is listed under and which classes get a launch.
+// k_dp_skew computes the plain recurrence, for which the striping is only a matter of row numbers: a kernel of S segments serves
+// any read whose padded row count fits into its 8 x S rows (ROW SHIFT at k_dp_skew).  So
+//   * a class with few reads does not get a launch of its own (~50 waves on a 1 024-SIMD chip cost what 20 000 cost -- r02, config 4:
+//     2 % of the jobs took 20 % of the DP stream time) but rides in the next populated class's, at that class's cost per read;
+//   * reverse passes, whose class (of the aligned PREFIX) is decided on the device, launch the classes c and c-1 of every forward
+//     class c and list every other prefix class under the next of those: no branch-guarded sweep launch is left.
+// n16wf / n16low / n8low: reads per class among the fast-gap reads (16-bit classes of the word-first reads and of the others; 8-bit
+// classes of the others).  Any map that sends a class to one at least as long is correct; this only moves work between launches.
+#define IPX_MERGE_BELOW 8192     // reads: a class with fewer is merged into the next kept class ...
+#define IPX_MERGE_TINY 1024      // ... unless that more than doubles its cost and it has at least this many reads
+static inline void ipx_merge_classes(const uint32_t *n, int top, bool merge, uint8_t *map, uint8_t *set)
+{
+    int target = -1;
+    for (int c = top; c >= 0; --c) {
+        if (!n[c]) continue;
+        const bool small = merge && n[c] < IPX_MERGE_BELOW && (2 * c >= target || n[c] < IPX_MERGE_TINY);
+        if (target >= 0 && (small || c == 0)) map[c] = (uint8_t)target;
+        else { target = c; set[c] = 1; map[c] = (uint8_t)c; }
+    }
+}
+// reverse pass: launches for c and c-1 of every kept forward class, every other prefix class listed under the next launch
+static inline void ipx_reverse_classes(const uint8_t *kept_a, const uint8_t *kept_b, int top, uint8_t *map, uint8_t *set)
+{
+    for (int c = 1; c <= top; ++c)
+        if (kept_a[c] || (kept_b && kept_b[c])) { set[c] = 1; if (c > 1) set[c - 1] = 1; }
+    int target = -1;
+    for (int c = top; c >= 0; --c) {
+        if (set[c]) target = c;
+        if (target >= 0) map[c] = (uint8_t)target;
+    }
+}
+static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
+{
+    for (int ps = 0; ps < IPX_NUM_PASSES; ++ps)
+        for (int c = 0; c < IPX_NUM_CLASSES; ++c) d.cls_map[ps][c] = (uint8_t)c;
+    memset(d.set, 0, sizeof d.set);
+    d.word_sets = d.plain_first = d.high_sets = 0;
+    const bool skew_ok = ipx_perm_profile_ok(b.mat, routing) && !(routing & (IPX_ROUTE_NO_F16 | IPX_ROUTE_NO_SKEW)) && b.f16_max_len > 0;
+    if (!skew_ok) return;
+    const bool merge = !(routing & IPX_ROUTE_NO_CLASS_MERGE);
+    uint32_t n16wf[IPX_MAX_SEG + 1], n16low[IPX_MAX_SEG + 1], n8low[IPX_MAX_SEG + 1];
+    memset(n16wf, 0, sizeof n16wf); memset(n16low, 0, sizeof n16low); memset(n8low, 0, sizeof n8low);
+    int top16 = -1, top8 = -1;
+    for (int len = 0; len <= IPX_MAX_READ_LEN; ++len) {
+        const uint32_t n = d.lenhist[0][len];
+        if (!n) continue;
+        const int c8 = (len + 15) / 16, c16 = (len + 7) / 8;
+        const bool wfirst = b.score_size == 2 && b.word_first_len > 0 && len >= b.word_first_len;
+        if (wfirst) n16wf[c16] += n; else { n16low[c16] += n; n8low[c8] += n; if (c8 > top8) top8 = c8; }
+        if (c16 > top16) top16 = c16;
+    }
+    // 16-bit passes: every fast-gap class must be within the wavefront kernels' reach (32 segments, scores exact in halves)
+    if (merge && b.score_size != 0 && top16 >= 1 && top16 <= IPX_MAX_EXACT && 8 * top16 <= b.f16_max_len) {
+        d.word_sets = 1;
+        ipx_merge_classes(n16wf, top16, true, d.cls_map[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST]);
+        ipx_merge_classes(n16low, top16, true, d.cls_map[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD]);
+        ipx_reverse_classes(d.set[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FWD], top16, d.cls_map[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV]);
+    }
+    // 8-bit passes as the plain recurrence: classes up to 16 segments of the 16-lane layout (= 32 of the 8-lane layout)
+    const bool plain_ok = b.score_size != 1 && top8 >= 1 && top8 <= 16 && 16 * top8 <= b.f16_max_len;
+    if (plain_ok && b.use_bracket && !(routing & IPX_ROUTE_NO_PLAIN_FIRST)) {
+        d.plain_first = 1;
+        ipx_merge_classes(n8low, top8, merge, d.cls_map[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST]);
+        if (merge) ipx_reverse_classes(d.set[IPX_PASS_BYTE_FIRST], nullptr, top8, d.cls_map[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN]);
+        else for (int c = 1; c <= top8; ++c) d.set[IPX_PASS_BYTE_REV_PLAIN][c] = 1, d.cls_map[IPX_PASS_BYTE_REV_PLAIN][0] = 1;
+    } else if (plain_ok && b.use_bracket) {
+        // bracket flow: the upper-bound stage as a wavefront (r02), its rare classes merged as well.  (Only reads that reach the
+        // bracket length get there; the counts of all 8-bit starters are an upper bound, which is all the merge rule needs.)
+        d.high_sets = 1;
+        ipx_merge_classes(n8low, top8, merge, d.cls_map[IPX_PASS_BYTE_HIGH], d.set[IPX_PASS_BYTE_HIGH]);
+    }
 }
 
 // scratch sizing shared by both back-ends -------------------------------------------------------

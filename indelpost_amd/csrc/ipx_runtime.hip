@@ -93,6 +93,7 @@ struct ipx_ctx {
     int64_t dp_grid_cap = 1;                    // DP blocks per launch (each owns a column-maxima scratch region)
     uint32_t prev_tiles[IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1)] = {0};   // planner tile counts of the previous run, per pass and class
     uint32_t *stats_dev = nullptr;              // ... and where the planner leaves them
+    uint8_t *cls_map_dev = nullptr;             // IpxBatch::cls_map (filled from IpxDims::cls_map when the static plans are built)
     bool prev_valid = false;
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
 };
@@ -194,7 +195,8 @@ struct HipBackend {
 };
 
 static const char *k_names[IPX_K_NUM] = {"init", "plan", "dp_byte_low", "dp_byte_check", "dp_byte_high", "dp_byte_exact", "dp_word_first",
-                                         "dp_word_fwd", "dp_byte_rev", "dp_word_rev", "tb_list", "traceback", "pack_refs", "prove_overflow"};
+                                         "dp_word_fwd", "dp_byte_rev", "dp_word_rev", "tb_list", "traceback", "pack_refs", "prove_overflow",
+                                         "dp_byte_plain", "dp_byte_low2", "dp_byte_rev_plain", "prove_plain"};
 
 extern "C" {
 
@@ -284,13 +286,12 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     const int64_t read_bytes = read_off[n_jobs], ref_bytes = ref_off[n_refs];
     // host-side geometry: packed (4-byte aligned, padded) window offsets and the batch maxima
     if (c->async_io) HIPCHK(hipStreamSynchronize(c->stream));   // (the previous upload's copies read h_refp / h_rlen)
-    std::vector<int64_t> &refp = c->h_refp;
-    std::vector<int32_t> &rlen = c->h_rlen;
-    refp.assign((size_t)n_refs + 1, 0);
-    rlen.assign((size_t)n_refs + 1, 0);
-    IpxDims &d = c->dims;
+    // Everything is validated into locals first: a rejected upload leaves the resident batch (and its plans) as they were.
+    std::vector<int64_t> refp((size_t)n_refs + 1, 0);
+    std::vector<int32_t> rlen((size_t)n_refs + 1, 0);
+    std::vector<IpxDims> dloc(1);
+    IpxDims &d = dloc[0];
     memset(&d, 0, sizeof d);
-    c->static_valid = false;
     int64_t tot = 0;
     for (int32_t r = 0; r < n_refs; ++r) {
         const int64_t len = ref_off[r + 1] - ref_off[r];
@@ -305,6 +306,10 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         ipx_dims_add_read(d, (int)len, gap_open[i] <= gap_ext[i]);
         if (ref_id[i] < 0 || ref_id[i] >= n_refs) { set_err("job %lld: ref_id %d out of range", (long long)i, ref_id[i]); return IPX_ERR_ARG; }
     }
+    c->h_refp.swap(refp);
+    c->h_rlen.swap(rlen);
+    c->dims = d;
+    c->static_valid = false;
     // launch sizes learned from the previous run only carry over to a batch of similar size
     if (c->prev_valid && (n_jobs > 2 * c->n_jobs || 2 * n_jobs < c->n_jobs)) c->prev_valid = false;
     c->n_jobs = n_jobs; c->n_refs = n_refs; c->have_mask = mask_len != nullptr;
@@ -317,7 +322,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
         c->perm.ensure(12 * (size_t)n_jobs + 16) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
         c->tb_esc.ensure(4 * (size_t)n_jobs + 4) ||
-        c->small.ensure(4 * ((size_t)IPX_PLAN_TABLE_WORDS + (size_t)IPX_NUM_PASSES * 3 * (IPX_NUM_CLASSES + 1) + IPX_NUM_CLASSES + 64)))
+        c->small.ensure(4 * ((size_t)IPX_PLAN_TABLE_WORDS + (size_t)IPX_NUM_PASSES * 3 * (IPX_NUM_CLASSES + 1) + IPX_NUM_CLASSES + 64 + (IPX_NUM_PASSES * IPX_NUM_CLASSES + 3) / 4)))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
     if (c->cigar_pool.ensure(4 * (size_t)c->cigar_cap)) return IPX_ERR_NO_DEVICE;
@@ -327,8 +332,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     HIPCHK(hipMemcpyAsync(c->read_off.p, read_off, 8 * ((size_t)n_jobs + 1), hipMemcpyHostToDevice, s));
     if (ref_bytes) HIPCHK(hipMemcpyAsync(c->refs_raw.p, refs, (size_t)ref_bytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->ref_off.p, ref_off, 8 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->refp_off.p, refp.data(), 8 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->ref_len.p, rlen.data(), 4 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->refp_off.p, c->h_refp.data(), 8 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ref_len.p, c->h_rlen.data(), 4 * ((size_t)n_refs + 1), hipMemcpyHostToDevice, s));
     if (n_jobs) {
         HIPCHK(hipMemcpyAsync(c->ref_id.p, ref_id, 4 * (size_t)n_jobs, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->gap_open.p, gap_open, (size_t)n_jobs, hipMemcpyHostToDevice, s));
@@ -402,6 +407,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb_esc_n = c->ws.tb_list_n + 7;
     uint32_t *cursor = sm; sm += 4;
     uint32_t *status = sm; sm += 4;
+    c->cls_map_dev = (uint8_t *)sm; sm += (IPX_NUM_PASSES * IPX_NUM_CLASSES + 3) / 4;
     HIPCHK(hipMemsetAsync(c->small.p, 0, 4 * (size_t)(sm - c->small.as<uint32_t>()), s));
 
     IpxBatch &b = c->batch;
@@ -439,7 +445,12 @@ int ipx_run(ipx_ctx *c)
     be.zero_u32(b.status, 1);
     if (!c->static_valid && c->n_jobs > 0) {
         // first run of this batch under these parameters: the job lists of the passes every job starts in
-        ipx_dims_finish(c->dims, b.word_first_len, c->score_size, ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
+        ipx_plan_classes(c->dims, b, c->routing);
+        b.plain_first = c->dims.plain_first;
+        b.cls_map = c->cls_map_dev;
+        HIPCHK(hipMemcpyAsync(c->cls_map_dev, &c->dims.cls_map[0][0], sizeof c->dims.cls_map, hipMemcpyHostToDevice, c->stream));
+        ipx_dims_finish(c->dims, b.word_first_len, c->score_size,
+                        b.plain_first ? 0 : ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
         const bool prof = c->profiling;
         c->profiling = false;
         ipx_build_static_plans(be, b, c->ws, c->dims, c->routing);

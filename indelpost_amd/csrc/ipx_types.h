@@ -30,6 +30,13 @@ enum {
     IPX_MODE_NEED_BYTE_CHECK = 6,  // ... and not provable from the diagonal: the 8-bit pass decides
     IPX_MODE_NEED_BYTE_EXACT_W = 7,// as NEED_BYTE_EXACT, with a 16-bit result already in the record
     IPX_MODE_NEED_BYTE_HIGH = 8,   // the record holds the LOWER-bound stage's outputs; the upper-bound stage certifies them or not
+    // "plain first" flow of the 8-bit passes (r03, see IPX_PASS_BYTE_FIRST): the plain recurrence runs FIRST and is certified afterwards
+    IPX_MODE_BYTE_PLAIN = 9,       // forward 8-bit result final AND equal to the plain recurrence's: the reverse pass may run as a wavefront
+    IPX_MODE_NEED_FWD_PROOF = 10,  // the record holds the plain recurrence's outputs; the best cell still needs its lower-bound proof
+    IPX_MODE_NEED_FWD_PROOF2 = 11, // ... and so does the second-best column
+    IPX_MODE_NEED_BYTE_LOW = 12,   // plain recurrence reached the overflow threshold: the lower-bound stage decides (nothing to compare with)
+    IPX_MODE_NEED_BYTE_LOW_CMP = 13,  // proof failed: the lower-bound stage runs and is compared with the plain outputs in the record
+    IPX_MODE_NEED_REV_PROOF = 14,  // begin position from the plain reverse recurrence in the record; its cell still needs the proof
     IPX_MODE_PENDING = 255,  // not processed yet
 };
 
@@ -40,7 +47,9 @@ enum {
 // k_prove_overflow), so that one scatter launch per pass is all the planning left on the stream.
 enum {
     IPX_PASS_WORD_FIRST = 0,      // static: 16-bit forward pass BEFORE the 8-bit one, for reads that will almost surely overflow
-    IPX_PASS_BYTE_LOW = 1,        // static: 8-bit forward pass, lower-bound stage, every other read
+    IPX_PASS_BYTE_FIRST = 1,      // static: the first 8-bit stage of every other read.  Bracket flow (r02): the lower-bound stage.  Plain-first
+                                  //   flow (r03, IpxBatch::plain_first): the plain recurrence as a wavefront (k_dp_skew BH = 2), an upper bound of
+                                  //   the 8-bit matrix cell by cell, certified afterwards by k_prove_plain (a banded lower bound through the best cell)
     IPX_PASS_BYTE_CHECK = 2,      // 8-bit lower-bound stage for word-first reads whose overflow could not be proven
     IPX_PASS_BYTE_HIGH = 3,       // 8-bit forward pass, upper-bound stage: certifies the lower-bound outputs
     IPX_PASS_BYTE_EXACT = 4,      // 8-bit forward pass with the reference's stepped lazy-F: what the bracket left open, and (a static
@@ -48,7 +57,9 @@ enum {
     IPX_PASS_WORD_FWD = 5,        // 16-bit forward pass after an 8-bit overflow (ssw.c:844-847)
     IPX_PASS_BYTE_REV = 6,
     IPX_PASS_WORD_REV = 7,
-    IPX_NUM_PASSES = 8,
+    IPX_PASS_BYTE_LOW2 = 8,       // plain-first flow: lower-bound stage for the reads whose plain result could not be certified by proof
+    IPX_PASS_BYTE_REV_PLAIN = 9,  // plain-first flow: 8-bit reverse pass as the plain recurrence (reads in IPX_MODE_BYTE_PLAIN), certified by proof
+    IPX_NUM_PASSES = 10,
     IPX_FIRST_DYNAMIC_PASS = 2,
     IPX_PASS_MC_LDS = 0x100,      // flag or-ed into a DP kernel's `pass` argument: column maxima live in LDS (room reserved by the launch)
 };
@@ -67,6 +78,8 @@ enum {
     IPX_ROUTE_NO_SKEW = 64,        // half-precision 16-bit passes column by column with lazy-F (k_dp_pass) instead of as a wavefront (k_dp_skew)
     IPX_ROUTE_NO_VL2 = 128,        // 8-bit lower-bound stage in the reference's 16-lane layout (8 reads per wave) instead of two reference
                                    //   lanes per GPU lane (16 reads per wave)
+    IPX_ROUTE_NO_PLAIN_FIRST = 256,  // 8-bit passes in the r02 bracket order (lower bound, upper bound, stepped) instead of plain recurrence + proof
+    IPX_ROUTE_NO_CLASS_MERGE = 512,  // every segLen class keeps its own wavefront launch (no rare class served by a longer class's kernel)
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 
@@ -100,6 +113,10 @@ struct IpxBatch {
     int32_t f16_max_len;        // reads up to this length may take the half-precision form of the 16-bit passes (k_dp_pass F16): every
                                 //   matrix entry is a half whose low byte is 0 and len * max(mat) <= 2047; 0 = never; speed only
     uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
+    uint8_t plain_first;        // the 8-bit passes of this batch take the plain-first flow (IPX_PASS_BYTE_FIRST): speed only
+    const uint8_t *cls_map;     // [IPX_NUM_PASSES][IPX_NUM_CLASSES] class a job of (pass, class) is LISTED under, or nullptr = its own.  The
+                                //   wavefront kernels serve any read whose padded row count fits theirs (rows shifted down, k_dp_skew), so a
+                                //   rare class rides in the next populated one's launch instead of getting a launch to itself: speed only
     uint8_t flag;               // ssw_align flag (ssw.c:821)
     uint8_t score_size;         // ssw_init score_size: 0 byte only, 1 word only, 2 both (ssw.c:793-802)
     uint16_t filters;

@@ -228,7 +228,10 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.byte_safe_len = ipx_byte_safe_len(mat, -bias);
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
-    ipx_dims_finish(d, b.word_first_len, score_size, ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
+    ipx_plan_classes(d, b, routing);
+    b.plain_first = d.plain_first;
+    b.cls_map = &d.cls_map[0][0];
+    ipx_dims_finish(d, b.word_first_len, score_size, b.plain_first ? 0 : ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
 
     b.maxcol_scratch = zalloc<uint32_t>((size_t)be.dp_grid() * 16 * (size_t)(d.max_ref_len + 8));
     IpxWorkspace ws;

@@ -74,7 +74,7 @@ class EmuAligner:
                                     self.score_size, self.routing, _p(rec), _p(pool), C.c_uint32(cap), C.byref(st), _p(launches), _p(pass_jobs))
         self.status = st.value
         self.launches = {int(k): int(launches[k]) for k in np.flatnonzero(launches)}
-        self.pass_jobs = pass_jobs[:8].tolist()     # jobs per pass (IPX_PASS_* order of csrc/ipx_types.h)
+        self.pass_jobs = pass_jobs[:10].tolist()    # jobs per pass (IPX_PASS_* order of csrc/ipx_types.h)
         used = int((rec["cigar_off"].astype(np.int64) + rec["cigar_len"]).max()) if n else 0
         return BatchResult(rec, pool[:used])
 

@@ -155,7 +155,8 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
 
 
 @pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE),
-                                   (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE)])
+                                   (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE), (R.ROUTE_NO_PLAIN_FIRST,),
+                                   (R.ROUTE_NO_CLASS_MERGE,), (R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_VL2)])
 def test_emu_routing_knobs_off(emu, golden_c, knobs):
     """The speed-only routing decisions (the upper-bound stage, 16-bit pass first, register-selector profile, column
     maxima in LDS, fused traceback launch) must not change any result: golden vectors with each turned off."""
@@ -178,6 +179,7 @@ def test_emu_routing_knobs_off(emu, golden_c, knobs):
 K_BYTE_LOW, K_BYTE_CHECK, K_BYTE_HIGH, K_BYTE_EXACT, K_WORD_FIRST, K_WORD_FWD, K_BYTE_REV, K_WORD_REV = range(2, 10)
 SLOW_BASE = 65
 K_PACK = 12
+K_BYTE_PLAIN, K_BYTE_LOW2, K_BYTE_REV_PLAIN, K_PROVE_PLAIN = 14, 15, 16, 17
 
 
 def _launched(a, kclass):
@@ -213,22 +215,33 @@ def test_emu_bracket_certifies_or_steps(emu, oracle_mod, port):
     for i, r in enumerate(reads):
         assert res.as_dict(i) == port.align(r, [w, lowc][refs_id[i]], mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])), i
     assert (res.records["mode"] == 0).all()                               # 8-bit semantics throughout
-    assert _launched(a, K_BYTE_LOW) == [5] and _launched(a, K_BYTE_HIGH) == [5] and _launched(a, K_WORD_FIRST) == []
+    # default (r03): the plain recurrence first (a wavefront at 2 x 5 segments, marker 2), then the proof kernel; only what the proof
+    # leaves open takes the lower-bound stage, and only what that cannot settle is stepped.  The reverse pass likewise.
+    assert _launched(a, K_BYTE_PLAIN) == [5] and _launched(a, K_BYTE_LOW) == [] and _launched(a, K_BYTE_HIGH) == [] and _launched(a, K_WORD_FIRST) == []
+    assert a.launches.get(a.key(K_PROVE_PLAIN, 0)) == 1 and a.launches.get(a.key(K_PROVE_PLAIN, 1)) == 1
+    n_first, n_low2, n_exact, n_rev, n_rev_plain = a.pass_jobs[1], a.pass_jobs[8], a.pass_jobs[4], a.pass_jobs[6], a.pass_jobs[9]
+    assert n_first == 28 and n_low2 < 14 and n_exact <= n_low2 and n_rev_plain >= 28 - n_low2 and n_rev + n_rev_plain >= 28 and n_rev < 14
+    # the r02 order (lower bound, upper bound, stepped): same records
+    o = emu(0, 3, 2)
+    o.set_routing(R.ROUTE_NO_PLAIN_FIRST)
+    res_o = o.align(jobs)
+    assert o.status == 0 and all(res_o.as_dict(i) == res.as_dict(i) for i in range(jobs.n_jobs))
+    assert _launched(o, K_BYTE_LOW) == [5] and _launched(o, K_BYTE_HIGH) == [5] and _launched(o, K_BYTE_PLAIN) == [] and _launched(o, K_WORD_FIRST) == []
     # both stages in halves: the lower bound column by column (marker 3), the upper bound as a wavefront at segLen 2 x 5 (marker 2)
     # (marker 4: the lower bound with two reference lanes per GPU lane, 16 reads per wave; marker 2: the upper bound as a wavefront at 2 x 5 segments)
-    assert {k % 256 for k in a.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 4 + 5, 10 + 40 * 2 + 10}
+    assert {k % 256 for k in o.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 4 + 5, 10 + 40 * 2 + 10}
     # the same batch in the reference's 16-lane layout (8 reads per wave): same records
     c = emu(0, 3, 2)
-    c.set_routing(R.ROUTE_NO_VL2)
+    c.set_routing(R.ROUTE_NO_VL2 | R.ROUTE_NO_PLAIN_FIRST)
     res_c = c.align(jobs)
     assert {k % 256 for k in c.launches if k // 256 == K_PACK and k % 256 >= 90} == {10 + 40 * 3 + 5, 10 + 40 * 2 + 10}
     assert all(res_c.as_dict(i) == res.as_dict(i) for i in range(jobs.n_jobs))
-    n_low, n_high, n_exact = a.pass_jobs[1], a.pass_jobs[3], a.pass_jobs[4]
+    n_low, n_high, n_exact = o.pass_jobs[1], o.pass_jobs[3], o.pass_jobs[4]
     assert n_low == 28 and n_high >= 20 and n_exact < n_high          # most of what reaches the upper-bound stage is certified
     b = emu(0, 3, 2)
     b.set_routing(R.ROUTE_NO_BRACKET)
     res2 = b.align(jobs)
-    assert _launched(b, K_BYTE_HIGH) == [] and b.pass_jobs[3] == 0 and b.pass_jobs[4] == n_high
+    assert _launched(b, K_BYTE_HIGH) == [] and _launched(b, K_BYTE_PLAIN) == [] and b.pass_jobs[3] == 0 and b.pass_jobs[4] == n_high
     for f in res.records.dtype.names:
         if f != "cigar_off":
             assert np.array_equal(res.records[f], res2.records[f]), f
