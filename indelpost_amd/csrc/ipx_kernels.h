@@ -1271,338 +1271,403 @@ template <int W> IPX_DEV pk16 group_minu(pk16 x)
 // waves per SIMD to ask for: segLen 20..25 sits just above the three-wave register budget (170) -- a few spilled values cost less
 // than the third wave brings (r02: config 4's 200 bp class); longer reads run at two waves
 IPX_HD constexpr int ipx_skew_waves(int smax, bool rev) { return (smax >= 20 && smax <= 25) ? 3 : (rev ? ipx_dp_perm_waves(smax) : 1); }
-template <int SMAX, bool REV, int BH = 0>
-IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
+// one tile of k_dp_skew: the 16 reads p.perm[first .. first + cnt)
+template <int SMAX, bool REV, int BH>
+IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
+                          unsigned char *lds, const uint32_t nz)
 {
     static_assert(!(BH == 1 && REV), "the upper-bound stage of the bracket is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
-    constexpr int W = 8, G = 8, NA = 16, S = SMAX;
+    constexpr int W = 8, G = 8, S = SMAX;
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
-    unsigned char *lds = IPX_LDS_BASE;
-    // LDS offset 0: [6 window letters][4 read letters], the high byte of each score as a half; looked up by byte offset (letter x 4)
-    const bool mc_lds = !REV && (pass & IPX_PASS_MC_LDS) != 0;
-    pass &= 0xFF;
-    uint32_t *maxcol = mc_lds ? (uint32_t *)(lds + 128) : b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);
-    if (lane < 24) {
-        const int v = lane < 20 ? b.mat[(lane >> 2) * 5 + (lane & 3)] : -2048;
-        ((int8_t *)lds)[lane] = (int8_t)((v == -2048 ? 0xE800u : ipx_f16_from_int(v)) >> 8);
+    // ---- per-slot parameters (index 0 = low half, 1 = high half of every packed register) ----
+    int64_t job[2];
+    int L[2], ncol[2], tb[2], idx0[2], kmax[2], score1[2], rend1[2];
+    const int8_t *rd[2];
+    const uint32_t *refw[2];
+    int gO[2], gE[2];
+    IPX_UNROLL
+    for (int h = 0; h < 2; ++h) {
+        const int slot = 2 * g + h;
+        job[h] = -1; L[h] = 0; ncol[h] = 0; tb[h] = 0; idx0[h] = 3; kmax[h] = 0; score1[h] = 0; rend1[h] = -1;
+        rd[h] = b.reads; refw[h] = (const uint32_t *)b.refs_packed; gO[h] = 1; gE[h] = 0;
+        if (slot < cnt) {
+            const int64_t jb = (int64_t)p.perm[first + slot];
+            const int rid = b.ref_id[jb];
+            const int refLen = b.ref_len[rid];
+            job[h] = jb;
+            rd[h] = b.reads + b.read_off[jb];
+            refw[h] = (const uint32_t *)(b.refs_packed + b.refp_off[rid]);
+            kmax[h] = ((refLen + 3) >> 2) + 1;
+            gO[h] = b.gap_open[jb];
+            gE[h] = b.gap_ext[jb];
+            if (!REV) {
+                L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
+                ncol[h] = refLen;
+            } else {
+                const IpxResult r = b.res[jb];
+                L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
+                ncol[h] = r.ref_end1 + 1; if (ncol[h] < 0) ncol[h] = 0;
+                score1[h] = r.score1;
+                rend1[h] = r.read_end1;
+                if (ncol[h] > 0) { idx0[h] = r.ref_end1 | 3; tb[h] = idx0[h] - r.ref_end1; }
+            }
+        }
     }
-    IPX_SYNC();
-    uint32_t nz = l == 0 ? 0u : 0xFFFFFFFFu;                        // what arrives from the lane above: nothing, in the first lane
-#if !defined(IPX_CPU_EMU)
-    asm volatile("" : "+v"(nz));                                    // (kept a register: v_and_b32 costs 2 cycles, the v_cndmask_b32 on a lane mask the compiler prefers 4)
-#endif
+    // rows the read is shifted down by: the kernel's row count minus the reference's padded row count for this read (ROW SHIFT above)
+    int dl[2];
+    IPX_UNROLL
+    for (int h = 0; h < 2; ++h) dl[h] = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
+    {   // this kernel has no stepped lazy-F and computes in halves: refuse what would need more (host-side routing error)
+        const bool bad = (job[0] >= 0 && (gO[0] <= gE[0] || L[0] > b.f16_max_len || dl[0] < 0)) ||
+                         (job[1] >= 0 && (gO[1] <= gE[1] || L[1] > b.f16_max_len || dl[1] < 0));
+        if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
+    }
+    const pk16 go = pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1]));     // -gapO, -gapE as halves
+    const pk16 ge = pk_make((int)ipx_f16_from_int(-gE[0]), (int)ipx_f16_from_int(-gE[1]));
+    const pk16 term = pk_make((int)ipx_f16_from_uint((uint32_t)score1[0]), (int)ipx_f16_from_uint((uint32_t)score1[1]));
 
-    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
-        if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
-        const uint32_t first = p.cls_off[cls] + want * NA;
-        const uint32_t avail = p.cls_off[cls + 1] - first;
-        const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
-
-        // ---- per-slot parameters (index 0 = low half, 1 = high half of every packed register) ----
-        int64_t job[2];
-        int L[2], ncol[2], tb[2], idx0[2], kmax[2], score1[2], rend1[2];
-        const int8_t *rd[2];
-        const uint32_t *refw[2];
-        int gO[2], gE[2];
+    // ---- selectors of the striped rows' read letters (k_dp_pass PERM) ----
+    pk16 SEL[SA];
+    {
+        int raw[2][SA];
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
-            const int slot = 2 * g + h;
-            job[h] = -1; L[h] = 0; ncol[h] = 0; tb[h] = 0; idx0[h] = 3; kmax[h] = 0; score1[h] = 0; rend1[h] = -1;
-            rd[h] = b.reads; refw[h] = (const uint32_t *)b.refs_packed; gO[h] = 1; gE[h] = 0;
-            if (slot < cnt) {
-                const int64_t jb = (int64_t)p.perm[first + slot];
-                const int rid = b.ref_id[jb];
-                const int refLen = b.ref_len[rid];
-                job[h] = jb;
-                rd[h] = b.reads + b.read_off[jb];
-                refw[h] = (const uint32_t *)(b.refs_packed + b.refp_off[rid]);
-                kmax[h] = ((refLen + 3) >> 2) + 1;
-                gO[h] = b.gap_open[jb];
-                gE[h] = b.gap_ext[jb];
-                if (!REV) {
-                    L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
-                    ncol[h] = refLen;
-                } else {
-                    const IpxResult r = b.res[jb];
-                    L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
-                    ncol[h] = r.ref_end1 + 1; if (ncol[h] < 0) ncol[h] = 0;
-                    score1[h] = r.score1;
-                    rend1[h] = r.read_end1;
-                    if (ncol[h] > 0) { idx0[h] = r.ref_end1 | 3; tb[h] = idx0[h] - r.ref_end1; }
-                }
-            }
-        }
-        // rows the read is shifted down by: the kernel's row count minus the reference's padded row count for this read (ROW SHIFT above)
-        int dl[2];
-        IPX_UNROLL
-        for (int h = 0; h < 2; ++h) dl[h] = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
-        {   // this kernel has no stepped lazy-F and computes in halves: refuse what would need more (host-side routing error)
-            const bool bad = (job[0] >= 0 && (gO[0] <= gE[0] || L[0] > b.f16_max_len || dl[0] < 0)) ||
-                             (job[1] >= 0 && (gO[1] <= gE[1] || L[1] > b.f16_max_len || dl[1] < 0));
-            if (xl_any(bad) && lane == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);
-        }
-        const pk16 go = pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1]));     // -gapO, -gapE as halves
-        const pk16 ge = pk_make((int)ipx_f16_from_int(-gE[0]), (int)ipx_f16_from_int(-gE[1]));
-        const pk16 term = pk_make((int)ipx_f16_from_uint((uint32_t)score1[0]), (int)ipx_f16_from_uint((uint32_t)score1[1]));
-
-        // ---- selectors of the striped rows' read letters (k_dp_pass PERM) ----
-        pk16 SEL[SA];
-        {
-            int raw[2][SA];
-            IPX_UNROLL
-            for (int h = 0; h < 2; ++h) {
-                IPX_UNROLL
-                for (int j = 0; j < SMAX; ++j) {
-                    const int r = j + l * S - dl[h];               // the read's row (ssw.c:178-185) held by this lane's segment j
-                    int idx = r < L[h] ? r : L[h] - 1;
-                    if (idx < 0) idx = 0;
-                    if (REV) idx = L[h] - 1 - idx;                 // reverse pass: seq_reverse (ssw.c:774-785)
-                    raw[h][j] = load_stream_i8(L[h] > 0 ? rd[h] + idx : (const int8_t *)b.read_off);
-                }
-            }
             IPX_UNROLL
             for (int j = 0; j < SMAX; ++j) {
-                uint32_t sel = 0;
-                IPX_UNROLL
-                for (int h = 0; h < 2; ++h) {
-                    const int r = j + l * S - dl[h];
-                    const unsigned base = (unsigned)raw[h][j];
-                    uint32_t sh = 0x0c0cu;                         // rows above the read, padding rows, letter N: constant 0
-                    if (r >= 0 && r < L[h] && base < 4u) sh = 0x000cu | ((base + 4u * h) << 8);   // high byte <- table byte 4*h + base
-                    sel |= sh << (16 * h);
-                }
-                SEL[j] = sel;
+                const int r = j + l * S - dl[h];               // the read's row (ssw.c:178-185) held by this lane's segment j
+                int idx = r < L[h] ? r : L[h] - 1;
+                if (idx < 0) idx = 0;
+                if (REV) idx = L[h] - 1 - idx;                 // reverse pass: seq_reverse (ssw.c:774-785)
+                raw[h][j] = load_stream_i8(L[h] > 0 ? rd[h] + idx : (const int8_t *)b.read_off);
             }
         }
-
-        // ---- DP state -----------------------------------------------------------------------------
-        pk16 H[SA], E[SA], HM[SA];
         IPX_UNROLL
-        for (int j = 0; j < SA; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
-        pk16 Hl_cur = 0, Hl_old = 0;           // this lane's last row after the previous step / the step before
-        pk16 vFend = 0;                        // F leaving this lane's last row, previous step
-        pk16 pm = 0;                           // maximum of this lane's column over the lanes up to this one
-        pk16 lbest = 0, lcol = 0;              // per lane: best H of its rows, first column with it (counted in processing order)
-        uint32_t let = 0x1414u;                // window letters of this lane's column, TIMES FOUR (= byte offsets into the score table; low byte:
-                                               //   low half's read), 5 = no column
-        pk16 ccol = pk_make(-l, -l);           // this lane's column, counted in processing order: t - l
-        pk16 seen = 0;                         // (reverse) this read was seen to have reached its score
-
-        const int T = (int)wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1])));
-        const int TT = T > 0 ? T + (W - 1) : 0;                    // the last lane is W-1 columns behind the first
-        uint32_t pairA = 0x14141414u, pairB = 0x14141414u;         // letters (x 4) of the first lane's next four columns: bytes (half 0, half 1) x 2 each
-        uint32_t cur[2], nxt[2];
-        IPX_UNROLL
-        for (int h = 0; h < 2; ++h) {
-            const int k0 = REV ? (idx0[h] >> 2) : 0;
-            int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
-            if (k1 < 0) k1 = 0;
-            if (k1 > kmax[h]) k1 = kmax[h];
-            cur[h] = load_global_u32(refw[h] + (k0 > kmax[h] ? kmax[h] : k0));
-            nxt[h] = load_global_u32(refw[h] + k1);
-        }
-
-        int tend = -1;                                              // (reverse) step at which every read has passed its last column
-        for (int t0 = 0; t0 < TT && (tend < 0 || t0 < tend); t0 += 4) {
-            if (t0 > 0) {
-                IPX_UNROLL
-                for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
-                IPX_VMEM_FENCE();
-                IPX_UNROLL
-                for (int h = 0; h < 2; ++h) {
-                    int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 1) : (t0 >> 2) + 1;
-                    if (k < 0) k = 0;
-                    if (k > kmax[h]) k = kmax[h];
-                    nxt[h] = load_global_u32(refw[h] + k);
-                }
-            }
-            if (REV && tend < 0) {
-                // A lane that holds the score the pass must reach got it in a column at or after the read's first such column,
-                // W-1 steps at most before every lane has been through that column: seen here, the read needs 7 more steps.
-                seen |= group_or<W>(~pk_nzmask(lbest ^ term));
-                const bool pending = (job[0] >= 0 && (seen & 0xFFFFu) == 0) || (job[1] >= 0 && (seen >> 16) == 0);
-                if (!xl_any(pending)) tend = t0 + (W - 1);
-            }
-            {   // the four columns of this group as the first lane will see them: letter x 4 (always a valid letter: windows are
-                // sanitised and padded), 5 x 4 outside the read's window; interleaved so that one v_perm_b32 per step picks a column
-                uint32_t x[2];
-                bool inside = true;                                  // all four columns inside both windows (the usual group)
-                IPX_UNROLL
-                for (int h = 0; h < 2; ++h) {
-                    x[h] = cur[h] << 2;
-                    inside = inside && t0 >= tb[h] && t0 + 4 <= tb[h] + ncol[h];
-                }
-                if (xl_any(!inside)) {
-                    IPX_UNROLL
-                    for (int h = 0; h < 2; ++h) {
-                        uint32_t vm = 0;
-                        IPX_UNROLL
-                        for (int k = 0; k < 4; ++k)
-                            if ((uint32_t)(t0 + k - tb[h]) < (uint32_t)ncol[h]) vm |= 0xFFu << (8 * (REV ? 3 - k : k));
-                        x[h] = (x[h] & vm) | (0x14141414u & ~vm);
-                    }
-                }
-                pairA = pk_perm(x[1], x[0], REV ? 0x06020703u : 0x05010400u);
-                pairB = pk_perm(x[1], x[0], REV ? 0x04000501u : 0x07030602u);
-            }
-            const int tn = t0 + 4 < TT ? t0 + 4 : TT;
-            IPX_NOUNROLL
-            for (int t = t0; t < tn; ++t) {
-                // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
-                const uint32_t ksel = (t & 1) ? 0x0c0c0302u : 0x0c0c0100u;
-                const uint32_t nl = pk_perm(0u, (t & 2) ? pairB : pairA, ksel);
-                const uint32_t up = xl_row_shr1(let);
-                let = l == 0 ? nl : up;
-                const uint32_t tab0 = *(const uint32_t *)(lds + (let & 0xFFu)), tab1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
-                // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
-                const pk16 vH = xl_row_shr1(Hl_old) & nz;
-                pk16 vF = xl_row_shr1(vFend) & nz;
-                const pk16 pmu = xl_row_shr1(pm) & nz;
-                pk16 cmx = 0;
-                dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
-                vFend = vF;
-                Hl_old = Hl_cur;
-                Hl_cur = H[SA - 1];
-                pm = pk_max(cmx, pmu);                               // (non-negative halves order like integers)
-                if (!REV && l == W - 1 && t >= W - 1) {              // column t-7 is complete
-                    if (mc_lds) maxcol[(t - (W - 1)) * G + g] = pm; else store_global_u32(maxcol + ((t - (W - 1)) * G + g), pm);
-                }
-                // -- this lane's best (ssw.c:521-539, per lane)
-                const pk16 nb = pk_max(lbest, cmx);
-                const pk16 dif = nb ^ lbest;                         // a half that is not 0: strictly better
-                lbest = nb;
-                if (xl_any(dif != 0)) {
-                    pk16 m = pk_nzmask(dif);
-                    // Reverse pass: the score to reach is the maximum of this matrix (it is the forward optimum, and every local
-                    // alignment inside the prefix rectangle is one of the forward matrix), so the one improvement whose column and
-                    // H values are ever looked at is the one that reaches it: no bookkeeping for the others.
-                    if (REV) m &= ~pk_nzmask(nb ^ term);
-                    if (!REV || xl_any(m != 0)) {
-                        lcol = pk_select(m, ccol, lcol);
-                        IPX_UNROLL
-                        for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);
-                    }
-                }
-                ccol = pk_add(ccol, 0x00010001u);
-            }
-        }
-
-        // ---- finalisation ---------------------------------------------------------------------------
-        IPX_SYNC();   // column maxima written by the last lane of each group are visible to the group
-        IPX_COMPILER_FENCE();
-        IPX_UNROLL
-        for (int h = 0; h < 2; ++h) {
-            const int slot = 2 * g + h;
-            job[h] = -1; L[h] = 0; ncol[h] = 0; score1[h] = 0; rend1[h] = -1; idx0[h] = 3;
-            if (slot < cnt) {
-                const int64_t jb = (int64_t)p.perm[first + slot];
-                job[h] = jb;
-                if (!REV) {
-                    L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
-                    ncol[h] = b.ref_len[b.ref_id[jb]];
-                } else {
-                    const IpxResult r = b.res[jb];
-                    L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
-                    score1[h] = r.score1;
-                    rend1[h] = r.read_end1;
-                    if (r.ref_end1 + 1 > 0) idx0[h] = r.ref_end1 | 3;
-                }
-            }
-        }
-        const pk16 bestA = group_max<W>(lbest);
-        const pk16 isb = ~pk_nzmask(lbest ^ bestA);                                  // lanes holding the read's best ...
-        const pk16 cminA = group_minu<W>(pk_select(isb, lcol, 0x7FFF7FFFu));          // ... the first column any of them has it in ...
-        const pk16 isc = isb & ~pk_nzmask(lcol ^ cminA);                             // ... and the lanes that have it there
-        IPX_UNROLL
-        for (int h = 0; h < 2; ++h) {
-            // end position on the read: smallest striped row holding `best` in that column (ssw.c:545-556), counted from the read's
-            // first row (ROW SHIFT: the rows above it hold 0, which is the best only when nothing scored -- row 0 then, as in the reference)
-            const unsigned bh = (bestA >> (16 * h)) & 0xFFFFu;
-            const bool mine = ((isc >> (16 * h)) & 0xFFFFu) != 0;
-            const int shift = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
-            uint32_t rmin = 0x7FFFFFFFu;
+        for (int j = 0; j < SMAX; ++j) {
+            uint32_t sel = 0;
             IPX_UNROLL
-            for (int j = SMAX - 1; j >= 0; --j)
-                if (mine && (((HM[j] >> (16 * h)) & 0xFFFFu) == bh)) rmin = (uint32_t)(j + l * S);
-            rmin = group_umin<W>(rmin);
-            int rrow = (int)rmin - shift;
-            if (rrow < 0) rrow = 0;
-            int end_read = L[h] - 1;
-            if (rrow < end_read) end_read = rrow;
-            const int cfirst = (int)((cminA >> (16 * h)) & 0xFFFFu);
-            const int eref = bh == 0 ? (BH ? -1 : 0) : (REV ? idx0[h] - cfirst : cfirst);   // (never improved: the initial 0 / -1, ssw.c:427 / 220)
-            const unsigned bv = ipx_f16_to_uint(bh);
-            if (REV && l == 0 && job[h] >= 0 && bv != (unsigned)score1[h]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);   // (cannot happen: see the column loop)
+            for (int h = 0; h < 2; ++h) {
+                const int r = j + l * S - dl[h];
+                const unsigned base = (unsigned)raw[h][j];
+                uint32_t sh = 0x0c0cu;                         // rows above the read, padding rows, letter N: constant 0
+                if (r >= 0 && r < L[h] && base < 4u) sh = 0x000cu | ((base + 4u * h) << 8);   // high byte <- table byte 4*h + base
+                sel |= sh << (16 * h);
+            }
+            SEL[j] = sel;
+        }
+    }
 
+    // ---- DP state -----------------------------------------------------------------------------
+    pk16 H[SA], E[SA], HM[SA];
+    IPX_UNROLL
+    for (int j = 0; j < SA; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
+    pk16 Hl_cur = 0, Hl_old = 0;           // this lane's last row after the previous step / the step before
+    pk16 vFend = 0;                        // F leaving this lane's last row, previous step
+    pk16 pm = 0;                           // maximum of this lane's column over the lanes up to this one
+    pk16 lbest = 0, lcol = 0;              // per lane: best H of its rows, first column with it (counted in processing order)
+    uint32_t let = 0x1414u;                // window letters of this lane's column, TIMES FOUR (= byte offsets into the score table; low byte:
+                                           //   low half's read), 5 = no column
+    pk16 ccol = pk_make(-l, -l);           // this lane's column, counted in processing order: t - l
+    pk16 seen = 0;                         // (reverse) this read was seen to have reached its score
+
+    const int T = (int)wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1])));
+    const int TT = T > 0 ? T + (W - 1) : 0;                    // the last lane is W-1 columns behind the first
+    uint32_t pairA = 0x14141414u, pairB = 0x14141414u;         // letters (x 4) of the first lane's next four columns: bytes (half 0, half 1) x 2 each
+    uint32_t cur[2], nxt[2];
+    IPX_UNROLL
+    for (int h = 0; h < 2; ++h) {
+        const int k0 = REV ? (idx0[h] >> 2) : 0;
+        int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
+        if (k1 < 0) k1 = 0;
+        if (k1 > kmax[h]) k1 = kmax[h];
+        cur[h] = load_global_u32(refw[h] + (k0 > kmax[h] ? kmax[h] : k0));
+        nxt[h] = load_global_u32(refw[h] + k1);
+    }
+
+    int tend = -1;                                              // (reverse) step at which every read has passed its last column
+    for (int t0 = 0; t0 < TT && (tend < 0 || t0 < tend); t0 += 4) {
+        if (t0 > 0) {
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
+            IPX_VMEM_FENCE();
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 1) : (t0 >> 2) + 1;
+                if (k < 0) k = 0;
+                if (k > kmax[h]) k = kmax[h];
+                nxt[h] = load_global_u32(refw[h] + k);
+            }
+        }
+        if (REV && tend < 0) {
+            // A lane that holds the score the pass must reach got it in a column at or after the read's first such column,
+            // W-1 steps at most before every lane has been through that column: seen here, the read needs 7 more steps.
+            seen |= group_or<W>(~pk_nzmask(lbest ^ term));
+            const bool pending = (job[0] >= 0 && (seen & 0xFFFFu) == 0) || (job[1] >= 0 && (seen >> 16) == 0);
+            if (!xl_any(pending)) tend = t0 + (W - 1);
+        }
+        {   // the four columns of this group as the first lane will see them: letter x 4 (always a valid letter: windows are
+            // sanitised and padded), 5 x 4 outside the read's window; interleaved so that one v_perm_b32 per step picks a column
+            uint32_t x[2];
+            bool inside = true;                                  // all four columns inside both windows (the usual group)
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                x[h] = cur[h] << 2;
+                inside = inside && t0 >= tb[h] && t0 + 4 <= tb[h] + ncol[h];
+            }
+            if (xl_any(!inside)) {
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t vm = 0;
+                    IPX_UNROLL
+                    for (int k = 0; k < 4; ++k)
+                        if ((uint32_t)(t0 + k - tb[h]) < (uint32_t)ncol[h]) vm |= 0xFFu << (8 * (REV ? 3 - k : k));
+                    x[h] = (x[h] & vm) | (0x14141414u & ~vm);
+                }
+            }
+            pairA = pk_perm(x[1], x[0], REV ? 0x06020703u : 0x05010400u);
+            pairB = pk_perm(x[1], x[0], REV ? 0x04000501u : 0x07030602u);
+        }
+        const int tn = t0 + 4 < TT ? t0 + 4 : TT;
+        IPX_NOUNROLL
+        for (int t = t0; t < tn; ++t) {
+            // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
+            const uint32_t ksel = (t & 1) ? 0x0c0c0302u : 0x0c0c0100u;
+            const uint32_t nl = pk_perm(0u, (t & 2) ? pairB : pairA, ksel);
+            const uint32_t up = xl_row_shr1(let);
+            let = l == 0 ? nl : up;
+            const uint32_t tab0 = *(const uint32_t *)(lds + (let & 0xFFu)), tab1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
+            // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
+            const pk16 vH = xl_row_shr1(Hl_old) & nz;
+            pk16 vF = xl_row_shr1(vFend) & nz;
+            const pk16 pmu = xl_row_shr1(pm) & nz;
+            pk16 cmx = 0;
+            dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
+            vFend = vF;
+            Hl_old = Hl_cur;
+            Hl_cur = H[SA - 1];
+            pm = pk_max(cmx, pmu);                               // (non-negative halves order like integers)
+            if (!REV && l == W - 1 && t >= W - 1) {              // column t-7 is complete
+                if (mc_lds) maxcol[(t - (W - 1)) * G + g] = pm; else store_global_u32(maxcol + ((t - (W - 1)) * G + g), pm);
+            }
+            // -- this lane's best (ssw.c:521-539, per lane)
+            const pk16 nb = pk_max(lbest, cmx);
+            const pk16 dif = nb ^ lbest;                         // a half that is not 0: strictly better
+            lbest = nb;
+            if (xl_any(dif != 0)) {
+                pk16 m = pk_nzmask(dif);
+                // Reverse pass: the score to reach is the maximum of this matrix (it is the forward optimum, and every local
+                // alignment inside the prefix rectangle is one of the forward matrix), so the one improvement whose column and
+                // H values are ever looked at is the one that reaches it: no bookkeeping for the others.
+                if (REV) m &= ~pk_nzmask(nb ^ term);
+                if (!REV || xl_any(m != 0)) {
+                    lcol = pk_select(m, ccol, lcol);
+                    IPX_UNROLL
+                    for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);
+                }
+            }
+            ccol = pk_add(ccol, 0x00010001u);
+        }
+    }
+
+    // ---- finalisation ---------------------------------------------------------------------------
+    IPX_SYNC();   // column maxima written by the last lane of each group are visible to the group
+    IPX_COMPILER_FENCE();
+    IPX_UNROLL
+    for (int h = 0; h < 2; ++h) {
+        const int slot = 2 * g + h;
+        job[h] = -1; L[h] = 0; ncol[h] = 0; score1[h] = 0; rend1[h] = -1; idx0[h] = 3;
+        if (slot < cnt) {
+            const int64_t jb = (int64_t)p.perm[first + slot];
+            job[h] = jb;
             if (!REV) {
-                // second best outside the mask window (ssw.c:568-581)
-                const int refLen = ncol[h];
-                const int maskLen = job[h] >= 0 ? mask_len_of(b, job[h], L[h]) : 15;
-                int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
-                int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
-                if (BH) edgeR += 1;                                   // ssw.c:374
-                uint32_t key2 = 0xFFFFu;                              // (score2 = 0, ref_end2 = 0)
-                uint32_t cbig = 0x7FFFFFFFu;                          // (BH = 2) first column holding a value >= 128
-                for (int col = l; col < refLen; col += W) {
-                    const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
-                    if (BH == 2 && v >= 0x5800u && cbig == 0x7FFFFFFFu) cbig = (uint32_t)col;      // (0x5800 = 128.0; non-negative halves order like integers)
-                    if (col < edgeL || col >= edgeR) {
-                        const uint32_t kk = (v << 16) | (0xFFFFu - (uint32_t)col);
-                        if (v > (key2 >> 16)) key2 = kk;
-                    }
-                }
-                key2 = group_umax<W>(key2);
-                if (BH == 2) cbig = group_umin<W>(cbig);
-                int key = -1;                                         // pass the job takes next (plan_note below)
-                if (l == 0 && job[h] >= 0) {
-                    IpxResult r = b.res[job[h]];
-                    const uint16_t s2 = (uint16_t)(maskLen >= 15 ? ipx_f16_to_uint(key2 >> 16) : 0u);         // ssw.c:864-870
-                    const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
-                    if (BH == 1) {
-                        // the record holds the lower-bound stage's outputs: equal outputs certify them (k_dp_pass STAGE); an upper
-                        // bound that reaches the overflow threshold certifies nothing
-                        const bool same = bv < (unsigned)(255 - b.bias) && r.score1 == (uint16_t)bv && r.ref_end1 == eref && r.read_end1 == end_read &&
-                                          r.score2 == s2 && r.ref_end2 == e2;
-                        r.mode = same ? IPX_MODE_BYTE : IPX_MODE_NEED_BYTE_EXACT;
-                        if (same) r.read_begin1 = -1;
-                    } else {
-                        r.score1 = (uint16_t)bv;
-                        r.ref_end1 = eref;
-                        r.read_end1 = end_read;
-                        r.read_begin1 = -1;
-                        r.score2 = s2;
-                        r.ref_end2 = e2;
-                        if (BH == 2) {
-                            // plain recurrence first (see BH = 2 above): below 128 nothing can reach the signed compare and the
-                            // result is the reference's; at the overflow threshold it says nothing; in between it is the candidate
-                            // k_prove_plain certifies -- the second-best column needs no proof when it was processed before any
-                            // value >= 128 existed (or is the initial 0)
-                            if (bv >= (unsigned)(255 - b.bias)) r.mode = IPX_MODE_NEED_BYTE_LOW;
-                            else if (bv < 128u) r.mode = rev_needed(b, bv) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE;
-                            else r.mode = (s2 == 0 || (e2 >= 0 && (uint32_t)e2 < cbig)) ? IPX_MODE_NEED_FWD_PROOF : IPX_MODE_NEED_FWD_PROOF2;
-                        } else r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
-                    }
-                    b.res[job[h]] = r;
-                    key = next_pass_key(b, r, L[h], false);
-                }
-                plan_note(b, key);
+                L[h] = (int)(b.read_off[jb + 1] - b.read_off[jb]);
+                ncol[h] = b.ref_len[b.ref_id[jb]];
             } else {
-                if (l == 0 && job[h] >= 0) {
-                    IpxResult r = b.res[job[h]];
-                    r.ref_begin1 = eref;                                                                       // ssw.c:885
-                    r.read_begin1 = rend1[h] - end_read;                                                       // ssw.c:886
-                    if ((unsigned)score1[h] > bv) r.flag = 2;                                                  // ssw.c:888-891
-                    // (BH = 2) the plain reverse recurrence: final below 128, otherwise k_prove_plain certifies the begin cell
-                    if (BH == 2) r.mode = score1[h] < 128 ? IPX_MODE_BYTE : IPX_MODE_NEED_REV_PROOF;
-                    b.res[job[h]] = r;
+                const IpxResult r = b.res[jb];
+                L[h] = r.read_end1 + 1; if (L[h] < 0) L[h] = 0;
+                score1[h] = r.score1;
+                rend1[h] = r.read_end1;
+                if (r.ref_end1 + 1 > 0) idx0[h] = r.ref_end1 | 3;
+            }
+        }
+    }
+    const pk16 bestA = group_max<W>(lbest);
+    const pk16 isb = ~pk_nzmask(lbest ^ bestA);                                  // lanes holding the read's best ...
+    const pk16 cminA = group_minu<W>(pk_select(isb, lcol, 0x7FFF7FFFu));          // ... the first column any of them has it in ...
+    const pk16 isc = isb & ~pk_nzmask(lcol ^ cminA);                             // ... and the lanes that have it there
+    IPX_UNROLL
+    for (int h = 0; h < 2; ++h) {
+        // end position on the read: smallest striped row holding `best` in that column (ssw.c:545-556), counted from the read's
+        // first row (ROW SHIFT: the rows above it hold 0, which is the best only when nothing scored -- row 0 then, as in the reference)
+        const unsigned bh = (bestA >> (16 * h)) & 0xFFFFu;
+        const bool mine = ((isc >> (16 * h)) & 0xFFFFu) != 0;
+        const int shift = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
+        uint32_t rmin = 0x7FFFFFFFu;
+        IPX_UNROLL
+        for (int j = SMAX - 1; j >= 0; --j)
+            if (mine && (((HM[j] >> (16 * h)) & 0xFFFFu) == bh)) rmin = (uint32_t)(j + l * S);
+        rmin = group_umin<W>(rmin);
+        int rrow = (int)rmin - shift;
+        if (rrow < 0) rrow = 0;
+        int end_read = L[h] - 1;
+        if (rrow < end_read) end_read = rrow;
+        const int cfirst = (int)((cminA >> (16 * h)) & 0xFFFFu);
+        const int eref = bh == 0 ? (BH ? -1 : 0) : (REV ? idx0[h] - cfirst : cfirst);   // (never improved: the initial 0 / -1, ssw.c:427 / 220)
+        const unsigned bv = ipx_f16_to_uint(bh);
+        if (REV && l == 0 && job[h] >= 0 && bv != (unsigned)score1[h]) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);   // (cannot happen: see the column loop)
+
+        if (!REV) {
+            // second best outside the mask window (ssw.c:568-581)
+            const int refLen = ncol[h];
+            const int maskLen = job[h] >= 0 ? mask_len_of(b, job[h], L[h]) : 15;
+            int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
+            int edgeR = eref + maskLen; if (edgeR > refLen) edgeR = refLen;
+            if (BH) edgeR += 1;                                   // ssw.c:374
+            uint32_t key2 = 0xFFFFu;                              // (score2 = 0, ref_end2 = 0)
+            uint32_t cbig = 0x7FFFFFFFu;                          // (BH = 2) first column holding a value >= 128
+            for (int col = l; col < refLen; col += W) {
+                const uint32_t v = (maxcol[col * G + g] >> (16 * h)) & 0xFFFFu;
+                if (BH == 2 && v >= 0x5800u && cbig == 0x7FFFFFFFu) cbig = (uint32_t)col;      // (0x5800 = 128.0; non-negative halves order like integers)
+                if (col < edgeL || col >= edgeR) {
+                    const uint32_t kk = (v << 16) | (0xFFFFu - (uint32_t)col);
+                    if (v > (key2 >> 16)) key2 = kk;
                 }
+            }
+            key2 = group_umax<W>(key2);
+            if (BH == 2) cbig = group_umin<W>(cbig);
+            int key = -1;                                         // pass the job takes next (plan_note below)
+            if (l == 0 && job[h] >= 0) {
+                IpxResult r = b.res[job[h]];
+                const uint16_t s2 = (uint16_t)(maskLen >= 15 ? ipx_f16_to_uint(key2 >> 16) : 0u);         // ssw.c:864-870
+                const int e2 = maskLen >= 15 ? (int)(0xFFFFu - (key2 & 0xFFFFu)) : -1;
+                if (BH == 1) {
+                    // the record holds the lower-bound stage's outputs: equal outputs certify them (k_dp_pass STAGE); an upper
+                    // bound that reaches the overflow threshold certifies nothing
+                    const bool same = bv < (unsigned)(255 - b.bias) && r.score1 == (uint16_t)bv && r.ref_end1 == eref && r.read_end1 == end_read &&
+                                      r.score2 == s2 && r.ref_end2 == e2;
+                    r.mode = same ? IPX_MODE_BYTE : IPX_MODE_NEED_BYTE_EXACT;
+                    if (same) r.read_begin1 = -1;
+                } else {
+                    r.score1 = (uint16_t)bv;
+                    r.ref_end1 = eref;
+                    r.read_end1 = end_read;
+                    r.read_begin1 = -1;
+                    r.score2 = s2;
+                    r.ref_end2 = e2;
+                    if (BH == 2) {
+                        // plain recurrence first (see BH = 2 above): below 128 nothing can reach the signed compare and the
+                        // result is the reference's; at the overflow threshold it says nothing; in between it is the candidate
+                        // k_prove_plain certifies -- the second-best column needs no proof when it was processed before any
+                        // value >= 128 existed (or is the initial 0)
+                        if (bv >= (unsigned)(255 - b.bias)) r.mode = IPX_MODE_NEED_BYTE_LOW;
+                        else if (bv < 128u) r.mode = rev_needed(b, bv) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE;
+                        else r.mode = (s2 == 0 || (e2 >= 0 && (uint32_t)e2 < cbig)) ? IPX_MODE_NEED_FWD_PROOF : IPX_MODE_NEED_FWD_PROOF2;
+                    } else r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
+                }
+                b.res[job[h]] = r;
+                key = next_pass_key(b, r, L[h], false);
+            }
+            plan_note(b, key);
+        } else {
+            if (l == 0 && job[h] >= 0) {
+                IpxResult r = b.res[job[h]];
+                r.ref_begin1 = eref;                                                                       // ssw.c:885
+                r.read_begin1 = rend1[h] - end_read;                                                       // ssw.c:886
+                if ((unsigned)score1[h] > bv) r.flag = 2;                                                  // ssw.c:888-891
+                // (BH = 2) the plain reverse recurrence: final below 128, otherwise k_prove_plain certifies the begin cell
+                if (BH == 2) r.mode = score1[h] < 128 ? IPX_MODE_BYTE : IPX_MODE_NEED_REV_PROOF;
+                b.res[job[h]] = r;
             }
         }
     }
 }
 
+// (tier kernels) the tile body as a CALL: inlined, the bodies of a tier share one register allocation and the longest one's spills
+// land in all of them; called, each keeps the allocation of its stand-alone kernel (the batch and plan descriptors travel by
+// reference, i.e. through private memory -- they are read in the tile's set-up and finalisation only, never in the column loop)
+#if defined(IPX_CPU_EMU)
+#define IPX_NOINLINE_DEV static
+#else
+#define IPX_NOINLINE_DEV __device__ __attribute__((noinline))
+#endif
+template <int SMAX, bool REV, int BH>
+IPX_NOINLINE_DEV void dp_skew_tile_call(const IpxBatch &b, const IpxPlan &p, const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
+                                        unsigned char *lds, const uint32_t nz)
+{
+    dp_skew_tile<SMAX, REV, BH>(b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
+}
+// (tier kernels) the tile body of class c, c a compile-time-unrollable value in [SLO / STEP, SHI / STEP]
+template <int SLO, int SHI, bool REV, int BH>
+IPX_DEV void dp_skew_tile_at(int c, const IpxBatch &b, const IpxPlan &p, uint32_t first, int cnt, int pass, uint32_t *maxcol, bool mc_lds, unsigned char *lds, uint32_t nz)
+{
+    constexpr int STEP = BH ? 2 : 1;
+    if constexpr (SLO <= SHI) {
+        if (c == SLO / STEP) dp_skew_tile_call<SLO, REV, BH>(b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
+        else dp_skew_tile_at<SLO + STEP, SHI, REV, BH>(c, b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
+    }
+}
+
+// prologue shared by the wavefront kernels: the score table in LDS (offset 0: [6 window letters][4 read letters], the high byte of each score
+// as a half, looked up by byte offset = letter x 4), this block's column maxima, the lane-0 mask
+#define IPX_SKEW_PROLOGUE                                                                                                             \
+    constexpr int W = 8, G = 8, NA = 16;                                                                                              \
+    const int lane = lane_id();                                                                                                       \
+    const int l = lane % W;                                                                                                           \
+    unsigned char *lds = IPX_LDS_BASE;                                                                                                \
+    const bool mc_lds = !REV && (pass & IPX_PASS_MC_LDS) != 0;                                                                        \
+    pass &= 0xFF;                                                                                                                     \
+    uint32_t *maxcol = mc_lds ? (uint32_t *)(lds + 128) : b.maxcol_scratch + (size_t)IPX_BID * (size_t)(G * maxcols);                 \
+    if (lane < 24) {                                                                                                                  \
+        const int v = lane < 20 ? b.mat[(lane >> 2) * 5 + (lane & 3)] : -2048;                                                        \
+        ((int8_t *)lds)[lane] = (int8_t)((v == -2048 ? 0xE800u : ipx_f16_from_int(v)) >> 8);                                          \
+    }                                                                                                                                 \
+    IPX_SYNC();                                                                                                                       \
+    uint32_t nz = l == 0 ? 0u : 0xFFFFFFFFu;       /* what arrives from the lane above: nothing, in the first lane */                 \
+    IPX_KEEP_VGPR(nz);                             /* (kept a register: v_and_b32 costs 2 cycles, the v_cndmask_b32 on a lane mask the compiler prefers 4) */
+
+template <int SMAX, bool REV, int BH = 0>
+IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
+{
+    IPX_SKEW_PROLOGUE
+    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
+        if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
+        const uint32_t first = p.cls_off[cls] + want * NA;
+        const uint32_t avail = p.cls_off[cls + 1] - first;
+        dp_skew_tile<SMAX, REV, BH>(b, p, first, avail < (uint32_t)NA ? (int)avail : NA, pass, maxcol, mc_lds, lds, nz);
+    }
+}
+
+// Several classes in ONE launch (r03).  A class launch that fills less than one round of wave slots lasts as long as its longest tile
+// whatever its size, and the kernels of a stream run one after the other: with five read-length classes per pass and a quarter of a
+// million jobs per stream, config 4 spent a third of every stream's time in the tails of launches the other streams could not fill
+// (the same table at twice the size ran 22 % faster per job).  A tier kernel holds the tile bodies of segLen SLO..SHI -- classes of one
+// occupancy -- and walks the tiles of the launch's classes in one grid: one ramp and one tail per tier instead of one per class.
+// set_mask: bit (class - cls_base) = the class is served by this launch (cls_base = SLO for the 16-bit passes, SLO / 2 in the 8-bit dialect).
+// waves per SIMD a tier asks for: what its longest class's stand-alone kernel runs at
+IPX_HD constexpr int ipx_tier_waves(int shi) { return shi <= 12 ? 4 : shi <= 25 ? 3 : 2; }
+template <int SLO, int SHI, bool REV, int BH = 0>
+IPX_KERNEL_WAVE_OCC(ipx_tier_waves(SHI)) void k_dp_skew_tier(IpxBatch b, IpxPlan p, uint32_t set_mask, int maxcols, int pass)
+{
+    constexpr int STEP = BH ? 2 : 1, C0 = SLO / STEP, C1 = SHI / STEP;             // classes of the tier
+    static_assert(SLO % STEP == 0 && SHI % STEP == 0 && C1 - C0 < 32, "tier bounds");
+    IPX_SKEW_PROLOGUE
+    int own_cls = C0;                                                 // class reached by the walk
+    uint32_t own_base = 0;                                            // owned tiles in the classes before own_cls
+    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
+        for (; own_cls <= C1; ++own_cls) {
+            const uint32_t n = ((set_mask >> (own_cls - C0)) & 1u) ? p.tile_off[own_cls + 1] - p.tile_off[own_cls] : 0u;
+            if (want < own_base + n) break;
+            own_base += n;
+        }
+        if (own_cls > C1) break;
+        const int cls = (int)xl_first((uint32_t)own_cls);
+        const uint32_t first = p.cls_off[cls] + (want - own_base) * NA;
+        const uint32_t avail = p.cls_off[cls + 1] - first;
+        const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
+        dp_skew_tile_at<SLO, SHI, REV, BH>(cls, b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
+    }
+}
 
 #if IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
@@ -2532,11 +2597,18 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
     X(18, REV, BH) X(20, REV, BH) X(22, REV, BH) X(24, REV, BH) X(26, REV, BH) X(28, REV, BH) X(30, REV, BH) X(32, REV, BH)
 #define IPX_SKEW_BH_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_SKEW_BH_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
+// tier kernels: several classes of one occupancy in one launch
+#define IPX_TIER_SIG (IpxBatch, IpxPlan, uint32_t, int, int)
+#define IPX_TIER_WORD(X, REV) X(1, 12, REV, 0) X(13, 19, REV, 0) X(20, 25, REV, 0) X(26, 32, REV, 0)
+#define IPX_TIER_BYTE(X, REV) X(2, 12, REV, 2) X(14, 24, REV, 2) X(26, 32, REV, 2)
+#define IPX_TIER_DEFINE(LO, HI, REV, BH) template __global__ void k_dp_skew_tier<LO, HI, REV, BH> IPX_TIER_SIG;
+#define IPX_TIER_EXTERN(LO, HI, REV, BH) extern template __global__ void k_dp_skew_tier<LO, HI, REV, BH> IPX_TIER_SIG;
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 #if defined(IPX_EXTERN_KERNELS)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
 IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 1) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 2) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, true, 2)
+IPX_TIER_WORD(IPX_TIER_EXTERN, false) IPX_TIER_WORD(IPX_TIER_EXTERN, true) IPX_TIER_BYTE(IPX_TIER_EXTERN, false) IPX_TIER_BYTE(IPX_TIER_EXTERN, true)
 IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H) IPX_DP_UNIT_M(IPX_DP_EXTERN_H) IPX_VL2_FAMILY(IPX_VL2_EXTERN)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)

@@ -224,16 +224,44 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uin
               ipx_dp_lds_bytes(W, IPX_MAX_SEG, REV, maxcols, false, routing), b, p, 0, last, maxcols, pass, exact[0], exact[1]);
 }
 
-// Wavefront launches of a pass whose (fast-gap) classes were planned by ipx_plan_classes: one k_dp_skew launch per class of `set`.
-// BH = 0: 16-bit passes, class c = c segments.  BH = 1 / 2: the plain recurrence in the 8-bit dialect, class c (8-bit segLen) = 2c
-// segments of the 8-lane layout.  A launch also serves the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).
+// Wavefront launches of a pass whose (fast-gap) classes were planned by ipx_plan_classes.  BH = 0: 16-bit passes, class c = c segments.
+// BH = 1 / 2: the plain recurrence in the 8-bit dialect, class c (8-bit segLen) = 2c segments of the 8-lane layout.  A launch also serves
+// the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).  The classes of `set` that fall into one occupancy
+// tier share ONE launch (k_dp_skew_tier) when there are at least two of them; a class alone in its tier keeps its own kernel.
+#define IPX_SUB_TIER 150      // timing sub-key of tier t: IPX_SUB_TIER + t
 template <class BE, bool REV, int BH>
 static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing)
 {
     const int lds = ipx_dp_lds_bytes(8, 0, REV, maxcols, true, routing);
     const int pflag = pass | (ipx_dp_mc_in_lds(8, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
+    uint8_t todo[IPX_MAX_EXACT + 1];
+    for (int c = 0; c <= IPX_MAX_EXACT; ++c) todo[c] = c <= (BH ? 16 : IPX_MAX_EXACT) ? set[c] : 0;
+    if (BH != 1 && !(routing & IPX_ROUTE_NO_TIERS)) {
+        // tiers in SEGMENTS (the template arguments of k_dp_skew_tier); classes are segments (BH = 0) or segments / 2
+        static const int word_tiers[4][2] = {{1, 12}, {13, 19}, {20, 25}, {26, 32}}, byte_tiers[3][2] = {{2, 12}, {14, 24}, {26, 32}};
+        const int nt = BH ? 3 : 4, step = BH ? 2 : 1;
+        for (int t = 0; t < nt; ++t) {
+            const int c0 = (BH ? byte_tiers[t][0] : word_tiers[t][0]) / step, c1 = (BH ? byte_tiers[t][1] : word_tiers[t][1]) / step;
+            uint32_t mask = 0;
+            int n = 0;
+            for (int c = c0; c <= c1; ++c) if (todo[c]) { mask |= 1u << (c - c0); ++n; }
+            if (n < 2) continue;
+            for (int c = c0; c <= c1; ++c) todo[c] = 0;
+            const int key = IPX_KEY(kclass, IPX_SUB_TIER + t);
+            be.note_dp_set(key, pass, c0, mask, 16);
+            for (int c = c0; c <= c1; ++c) if ((mask >> (c - c0)) & 1u) be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
+            const int grid = be.dp_grid_set(pass, c0, mask);
+#define IPX_TIER_CASE(T, LO, HI) case T: be.launch(key, k_dp_skew_tier<LO, HI, REV, BH>, grid, 64, lds, b, p, mask, maxcols, pflag); break;
+            if constexpr (BH == 0) {
+                switch (t) { IPX_TIER_CASE(0, 1, 12) IPX_TIER_CASE(1, 13, 19) IPX_TIER_CASE(2, 20, 25) IPX_TIER_CASE(3, 26, 32) default: break; }
+            } else if constexpr (BH == 2) {
+                switch (t) { IPX_TIER_CASE(0, 2, 12) IPX_TIER_CASE(1, 14, 24) IPX_TIER_CASE(2, 26, 32) default: break; }
+            }
+#undef IPX_TIER_CASE
+        }
+    }
     for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
-        if (!set[c]) continue;
+        if (!todo[c]) continue;
         be.note_dp(IPX_KEY(kclass, c), pass, c, 16);
         be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
 #define IPX_SK_CASE(C)                                                                                                         \
@@ -497,8 +525,10 @@ static inline void ipx_dims_finish(IpxDims &d, int word_first_len, int score_siz
 //     class c and list every other prefix class under the next of those: no branch-guarded sweep launch is left.
 // n16wf / n16low / n8low: reads per class among the fast-gap reads (16-bit classes of the word-first reads and of the others; 8-bit
 // classes of the others).  Any map that sends a class to one at least as long is correct; this only moves work between launches.
+#ifndef IPX_MERGE_BELOW          // (the emulator build sets small values so that its small batches keep several classes)
 #define IPX_MERGE_BELOW 8192     // reads: a class with fewer is merged into the next kept class ...
 #define IPX_MERGE_TINY 1024      // ... unless that more than doubles its cost and it has at least this many reads
+#endif
 static inline void ipx_merge_classes(const uint32_t *n, int top, bool merge, uint8_t *map, uint8_t *set)
 {
     int target = -1;

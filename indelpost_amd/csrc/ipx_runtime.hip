@@ -87,6 +87,7 @@ struct ipx_ctx {
     int k_launches[IPX_NUM_KEYS];
     int64_t k_units[IPX_NUM_KEYS];              // alignments the launches of a DP timing key processed (planner tile counts x tile size)
     int32_t k_dp_src[IPX_NUM_KEYS];             // DP timing key -> (pass * 256 + class) * 32 + alignments per tile, or -1
+    uint32_t k_dp_mask[IPX_NUM_KEYS];           // ... and the classes the launch serves: class + (bits set)
     int runs_since_sync = 0;                    // ipx_run calls the next ipx_sync accounts for (same batch: same tile counts each)
     hipEvent_t run_start = nullptr, run_stop = nullptr;
     float last_run_ms = 0.f;
@@ -147,7 +148,15 @@ struct HipBackend {
         const int64_t cap = (int64_t)c->num_cu * 8;
         return (int)(g < cap ? g : cap);
     }
-    void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 256 + cls) * 32 + na; }
+    void note_dp(int key, int pass, int cls, int na) { c->k_dp_src[key] = (pass * 256 + cls) * 32 + na; c->k_dp_mask[key] = 1u; }
+    // a launch that serves the classes base + (bits of mask)
+    void note_dp_set(int key, int pass, int base, uint32_t mask, int na) { c->k_dp_src[key] = (pass * 256 + base) * 32 + na; c->k_dp_mask[key] = mask; }
+    int dp_grid_set(int pass, int base, uint32_t mask) const
+    {
+        int64_t t = 0;
+        for (int k = 0; k < 32; ++k) if ((mask >> k) & 1u) t += c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + base + k];
+        return sized(t);
+    }
     void note_f16(int, int) {}
     void copy_u32(uint32_t *dst, const uint32_t *src, int n)
     {
@@ -228,6 +237,7 @@ ipx_ctx *ipx_create(int device)
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(c->k_units, 0, sizeof c->k_units);
     memset(c->k_dp_src, 0xFF, sizeof c->k_dp_src);
+    memset(c->k_dp_mask, 0, sizeof c->k_dp_mask);
     // default scoring: SSW() class defaults, match 2 / mismatch 2 (sswpy.pyx:112)
     static const int8_t dflt[25] = {2, -2, -2, -2, 0, -2, 2, -2, -2, 0, -2, -2, 2, -2, 0, -2, -2, -2, 2, 0, 0, 0, 0, 0, 0};
     memcpy(c->mat, dflt, 25);
@@ -495,7 +505,9 @@ int ipx_sync(ipx_ctx *c)
             for (int k = 0; k < IPX_NUM_KEYS; ++k)
                 if (c->k_dp_src[k] >= 0) {
                     const int na = c->k_dp_src[k] & 31, pc = c->k_dp_src[k] >> 5;
-                    c->k_units[k] += (int64_t)c->prev_tiles[(pc >> 8) * (IPX_NUM_CLASSES + 1) + (pc & 255)] * na * c->runs_since_sync;
+                    for (int q = 0; q < 32; ++q)
+                        if ((c->k_dp_mask[k] >> q) & 1u)
+                            c->k_units[k] += (int64_t)c->prev_tiles[(pc >> 8) * (IPX_NUM_CLASSES + 1) + (pc & 255) + q] * na * c->runs_since_sync;
                 }
     }
     c->runs_since_sync = 0;
@@ -610,6 +622,7 @@ const char *ipx_kernel_class_name(int k)
     const int kc = k / 256, sub = k % 256;
     if (ipx_k_is_dp(kc)) {
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
+        else if (sub >= IPX_SUB_TIER) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub - IPX_SUB_TIER);
         else if (sub >= IPX_SLOW_BASE) snprintf(buf, sizeof buf, "%s_slowgap_s%d", k_names[kc], sub - IPX_SLOW_BASE);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
     } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub == 10) snprintf(buf, sizeof buf, "%s_fast_bw4to7", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }

@@ -28,6 +28,7 @@ struct uint2 { uint32_t x, y; };
 #define IPX_COMPILER_FENCE() ((void)0)
 #define IPX_NOUNROLL
 #define IPX_RESTRICT
+#define IPX_KEEP_VGPR(x) ((void)0)
 namespace ipx_emu {
 struct LaneCtx { int tid; int bid; int gdim; int bdim; unsigned char *lds; };
 LaneCtx &cur();
@@ -157,6 +158,8 @@ IPX_DEV pk16 pkh_max3(pk16 a, pk16 b, pk16 c) { return pkh_max(pkh_max(a, b), c)
 // the compiler may not carry memory values (or move memory operations) across this point
 #define IPX_COMPILER_FENCE() asm volatile("" ::: "memory")
 #define IPX_RESTRICT __restrict__
+// keep a value in a vector register of its own (the compiler may not re-derive it from a lane mask)
+#define IPX_KEEP_VGPR(x) asm volatile("" : "+v"(x))
 #define IPX_TID ((int)threadIdx.x)
 #define IPX_BID ((int)blockIdx.x)
 #define IPX_GDIM ((int)gridDim.x)

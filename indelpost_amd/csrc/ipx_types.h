@@ -80,6 +80,7 @@ enum {
                                    //   lanes per GPU lane (16 reads per wave)
     IPX_ROUTE_NO_PLAIN_FIRST = 256,  // 8-bit passes in the r02 bracket order (lower bound, upper bound, stepped) instead of plain recurrence + proof
     IPX_ROUTE_NO_CLASS_MERGE = 512,  // every segLen class keeps its own wavefront launch (no rare class served by a longer class's kernel)
+    IPX_ROUTE_NO_TIERS = 1024,       // one wavefront launch per class even where several classes of one occupancy could share a launch (k_dp_skew_tier)
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 

@@ -55,16 +55,22 @@ def bench_name(k):
         else:
             base = "dp_word_rev" if rev else "dp_word_fwd"
         return "%s_%s" % (base, ("s%d" % s) if exact else "long")
-    m = re.match(r"void k_dp_skew<(\d+), (true|false)(?:, (true|false))?>", k)
+    m = re.match(r"void k_dp_skew<(\d+), (true|false)(?:, (\d+|true|false))?>", k)
     if m:
-        if m.group(3) == "true":                                   # the 8-bit upper-bound stage at segLen8 = S / 2
+        bh = {"true": 1, "false": 0, None: 0}.get(m.group(3), None)
+        bh = int(m.group(3)) if bh is None else bh
+        rev = m.group(2) == "true"
+        if bh == 1:                                                # the 8-bit upper-bound stage at segLen8 = S / 2 (bracket flow)
             return "dp_byte_high_s%d" % (int(m.group(1)) // 2)
-        return "%s_s%s" % ("dp_word_rev" if m.group(2) == "true" else "dp_word_fwd", m.group(1))
+        if bh == 2:                                                # the plain recurrence in the 8-bit dialect (plain-first flow)
+            return "%s_s%d" % ("dp_byte_rev_plain" if rev else "dp_byte_plain", int(m.group(1)) // 2)
+        return "%s_s%s" % ("dp_word_rev" if rev else "dp_word_fwd", m.group(1))
     m = re.match(r"void k_tb_fast<(\d+)>", k)
     if m:
         return "traceback_fast_bw%s" % m.group(1)
     for a, b in (("k_tb_coop", "traceback_tier1"), ("k_plan", "plan"), ("k_tb_list", "tb_list"),
-                 ("k_prove_overflow", "prove_overflow"), ("k_init", "init")):
+                 ("k_prove_overflow", "prove_overflow"), ("k_init", "init"), ("void k_prove_plain<false>", "prove_plain_fwd"),
+                 ("void k_prove_plain<true>", "prove_plain_rev")):
         if k.startswith(a):
             return b
     return k.split("(")[0]
@@ -127,7 +133,7 @@ def one(root, tag, w):
         for k in ks[:16]:
             n = cols["SQ_INSTS_VALU"][k][0]
             name = bench_name(k)
-            alias = [a for a in per_launch if a == name or a.replace("dp_word_first", "dp_word_fwd").replace("dp_byte_check", "dp_byte_low") == name]
+            alias = [a for a in per_launch if a == name or a.replace("dp_word_first", "dp_word_fwd").replace("dp_byte_check", "dp_byte_low").replace("dp_byte_low2", "dp_byte_low") == name]
             u = max([per_launch[a] for a in alias], default=0)
             valu = cols["SQ_INSTS_VALU"][k][1] / max(1, n)
             o.write("| `%s` | %s | %d | %s | %s | %s |\n" % (k[:60], name, n, u or "", ("%.0f" % (valu / u)) if u else "",
@@ -139,7 +145,7 @@ def one(root, tag, w):
         e = out["kernels"].setdefault(name, {"valu_insts_per_launch": 0})
         if int(v / max(1, n)) > e["valu_insts_per_launch"]:
             e["valu_insts_per_launch"] = int(v / max(1, n))
-            alias = [a for a in per_launch if a.replace("dp_word_first", "dp_word_fwd").replace("dp_byte_check", "dp_byte_low") == name]
+            alias = [a for a in per_launch if a.replace("dp_word_first", "dp_word_fwd").replace("dp_byte_check", "dp_byte_low").replace("dp_byte_low2", "dp_byte_low") == name]
             if alias:
                 out["alignments_per_launch"][name] = max(per_launch[a] for a in alias)
     out["note"] = "bench.py --workload %s --steps 2 --warmup 1 --streams 1" % w

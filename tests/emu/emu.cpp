@@ -171,6 +171,8 @@ struct EmuBackend {
     void zero_u32(uint32_t *p, int n) { memset(p, 0, sizeof(uint32_t) * (size_t)n); }
     void copy_u32(uint32_t *dst, const uint32_t *src, int n) { memcpy(dst, src, sizeof(uint32_t) * (size_t)n); }
     void note_dp(int, int, int, int) {}
+    void note_dp_set(int, int, int, uint32_t, int) {}
+    int dp_grid_set(int, int, uint32_t) const { return 3; }
     void note_f16(int kind, int S) { ++launches[IPX_KEY(IPX_K_PACK, 10 + 40 * kind + S)]; }   // (test visibility, under unused keys: half-precision launches per segLen; kind 0 16-bit column by column, 1 16-bit wavefront, 2 8-bit upper bound as a wavefront, 3 8-bit lower bound)
     template <class K, class... A>
     void launch(int kclass, K kern, int grid, int block, int lds, A... args)

@@ -273,8 +273,16 @@ def test_emu_slow_gap_jobs_are_a_class_of_their_own(emu, oracle_mod, port):
         assert res.as_dict(i) == port.align(r, w, mat, go[i], ge[i]), i
     wf = _launched(a, K_WORD_FIRST)
     assert any(c < SLOW_BASE for c in wf) and any(c >= SLOW_BASE for c in wf)     # 150 bp reads: fast and slow classes side by side
-    low = _launched(a, K_BYTE_LOW)
-    assert any(c < SLOW_BASE for c in low) and any(c >= SLOW_BASE for c in low)   # 60 bp reads likewise
+    # 60 bp reads: the fast-gap ones take the plain recurrence first, the slow-gap ones the stepped pass at once (r03) ...
+    assert _launched(a, K_BYTE_PLAIN) and all(c < SLOW_BASE for c in _launched(a, K_BYTE_PLAIN))
+    assert any(c >= SLOW_BASE for c in _launched(a, K_BYTE_EXACT)) and _launched(a, K_BYTE_LOW) == []
+    # ... and in the r02 order both take the lower-bound stage, in classes of their own
+    o = emu(0, 3, 2)
+    o.set_routing(R.ROUTE_NO_PLAIN_FIRST)
+    res_o = o.align(jobs)
+    assert o.status == 0 and all(res_o.as_dict(i) == res.as_dict(i) for i in range(len(reads)))
+    low = _launched(o, K_BYTE_LOW)
+    assert any(c < SLOW_BASE for c in low) and any(c >= SLOW_BASE for c in low)
 
 
 def test_emu_band_doubling_stays_in_the_lane_per_job_kernels(emu, oracle_mod, port):
@@ -349,3 +357,55 @@ def test_emu_half_precision_and_wavefront_forms_of_the_16_bit_passes(emu, oracle
             out.append(res)
         assert all(out[0].as_dict(i) == out[1].as_dict(i) == out[2].as_dict(i) for i in range(len(reads)))
         _compare(out[0], [(r, (w, w2)[k], go, ge) for r, k, go, ge in zip(reads, rid, gos, ges)], port, mat)
+
+
+def test_emu_rare_classes_ride_along_and_tiers_share_a_launch(emu, oracle_mod, port):
+    """r03: (1) a segLen class with few reads is listed under the next populated class and served by that class's wavefront
+    kernel with its rows shifted down (IpxBatch::cls_map, k_dp_skew ROW SHIFT) -- forward and reverse, 16-bit and plain 8-bit;
+    (2) the classes of one occupancy tier share ONE launch (k_dp_skew_tier).  Same records with either switched off, equal to
+    the oracle; empty reads and reads that end before their window does are in the mix (their reverse prefix is much shorter
+    than the read: a class of its own, decided on the device)."""
+    rng = np.random.default_rng(99)
+    wins = [rng.integers(0, 4, n).astype(np.int8) for n in (333, 210, 97)]
+    reads, rid, go, ge = [], [], [], []
+    lens = [150] * 14 + [100] * 10 + [104] * 2 + [131] * 2 + [75] * 8 + [61] * 2 + [33] * 2 + [250] * 6 + [201, 1, 0, 7]
+    for i, ln in enumerate(lens):
+        k = i % 3
+        w = wins[k]
+        ln = min(ln, len(w))
+        st = int(rng.integers(0, len(w) - ln + 1))
+        r = w[st:st + ln].copy()
+        for q in np.flatnonzero(rng.random(ln) < 0.03):
+            r[q] = rng.integers(0, 5)
+        if i % 4 == 1 and ln > 40:
+            r = np.concatenate([r[:ln // 2], r[ln // 2 + 3:]])
+        if i % 4 == 2 and ln > 40:
+            r = np.concatenate([r[:ln // 3], rng.integers(0, 4, 2).astype(np.int8), r[ln // 3:]])
+        if i % 7 == 3 and ln > 60:
+            r = np.concatenate([r[:ln // 2], rng.integers(0, 4, ln - ln // 2).astype(np.int8)])      # second half random: the alignment ends early
+        reads.append(r); rid.append(k)
+        g = [(3, 1), (5, 0), (4, 1), (3, 0)][i % 4]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, wins, rid, go, ge, encoded=True)
+    for ms, mm in ((3, 2), (1, 1)):
+        mat = oracle_mod.dna_matrix(ms, mm)
+        out = {}
+        for routing in (0, R.ROUTE_NO_TIERS, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_CLASS_MERGE | R.ROUTE_NO_PLAIN_FIRST):
+            a = emu(0, ms, mm)
+            a.set_routing(routing)
+            out[routing] = (a, a.align(jobs))
+            assert a.status == 0
+        base = out[0][1]
+        for routing, (a, res) in out.items():
+            assert all(res.as_dict(i) == base.as_dict(i) for i in range(jobs.n_jobs)), routing
+        _compare(base, [(r, wins[k], o_, e_) for r, k, o_, e_ in zip(reads, rid, go, ge)], port, mat)
+        a0, a1, a2 = out[0][0], out[R.ROUTE_NO_TIERS][0], out[R.ROUTE_NO_CLASS_MERGE][0]
+        tier = lambda a, kc: [k % 256 for k in a.launches if k // 256 == kc and k % 256 >= 150 and k % 256 < 160]
+        if ms == 3:
+            # 16-bit forward first: classes 13 (100 + the 104s), 17 (131), 19, 32 (250 + 201) ... rare ones merged away; 13..19 share tier 1
+            assert tier(a0, K_WORD_FIRST) and not tier(a1, K_WORD_FIRST)
+            assert len(_launched(a1, K_WORD_FIRST)) < len(_launched(a2, K_WORD_FIRST))        # merged classes: fewer launches
+            assert not [c for c in _launched(a1, K_WORD_REV) if c == 140]                   # no branch-guarded sweep launch left for the reverse pass
+        else:
+            assert tier(a0, K_BYTE_PLAIN) and not tier(a1, K_BYTE_PLAIN)
+            assert (base.records["mode"] == 0).all()
