@@ -95,6 +95,7 @@ def is_covering_target(readname, read_seq, indel_seq, mut_ref_lt, mut_ref_mid, m
     if len(toks) > 1:
         return 0
     unit = to_minimal_repeat_unit(indel_seq)
+    int(toks[0][:-1])                                                  # (mapped_len, :314: unused, but an empty CIGAR raises here as it does there)
     lt_len, mid_len = len(mut_ref_lt), len(mut_ref_mid)
     consumed = read_aln_end - read_aln_start + 1
     from_read_start, to_read_end = read_aln_start == 0, read_aln_end == read_seq_len - 1
@@ -170,3 +171,185 @@ def find_targets_by_ssw(read_seqs, realign_mask, indel_seq, n_repeats, mut_ref_l
     for i, p in zip(idx, pairs):
         out[i] = p
     return is_target, undetermined, out
+
+
+# =====================================================================================================================
+# find_by_smith_waterman_realn as ONE function with the reference's signature (localn.pyx:15-68): the alignment-independent
+# filters (findall_mismatches :71-136, is_worth_realn :139-220), the two alignments per remaining read as one GPU batch, and
+# the verdict written into the read dicts exactly as is_target_by_ssw does (:223-291).  parse_read_by_mut_aln (:475-539)
+# is the decomposition of a read along its mutant-contig alignment (the reference defines it but calls it nowhere).
+# Parity: pinned by vectors from the reference's own function text run against duck-typed reads / contigs with
+# make_aligner / align bound to the oracle (oracle/gen_driver_golden.py, tests/golden/driver_cases.json).
+# =====================================================================================================================
+def findall_mismatches(read, end_trim=0):
+    """read["mismatches"] = [(pos, ref base, read base, quality)] over the read's mapped blocks (localn.pyx:71-136)"""
+    from .pileup import get_mapped_subreads, split
+    if read["is_reference_seq"]:
+        read["mismatches"] = []
+        return read
+    aln_start, aln_end = read["aln_start"], read["aln_end"]
+    out = []
+    for start, end in get_mapped_subreads(read["cigar_string"], aln_start, aln_end):
+        span = end - start + 1
+        cigarstring = read["cigar_string"]
+        read_seq, quals = read["read_seq"], read["read_qual"]
+        if "S" in cigarstring:                                       # soft clips are cut off both the CIGAR and the read
+            cigarlst = read["cigar_list"]
+            if "S" in cigarlst[0]:
+                cigarlst = cigarlst[1:]
+                read_seq, quals = read_seq[read["start_offset"]:], quals[read["start_offset"]:]
+            if "S" in cigarlst[-1]:
+                cigarlst = cigarlst[:-1]
+                read_seq, quals = read_seq[:-read["end_offset"]], quals[:-read["end_offset"]]
+            cigarstring = "".join(cigarlst)
+        lt_seq, rt_seq = split(read_seq, cigarstring, start, aln_start, is_for_ref=False, reverse=False)
+        lt_qual, rt_qual = split(quals, cigarstring, start, aln_start, is_for_ref=False, reverse=False)
+        lt_ref, rt_ref = split(read["ref_seq"], cigarstring, start, aln_start, is_for_ref=True, reverse=False)
+        mapped_seq = lt_seq[-1] + rt_seq[:span - 1]
+        mapped_qual = [lt_qual[-1]] + list(rt_qual[:span - 1])
+        mapped_ref = lt_ref[-1] + rt_ref[:span - 1]
+        pos = start
+        for r, a, q in zip(mapped_ref, mapped_seq, mapped_qual):
+            if r != a and aln_start + end_trim <= pos <= aln_end - end_trim:
+                out.append((pos, r.upper(), a, q))
+            pos += 1
+    read["mismatches"] = out
+    return read
+
+
+def is_worth_realn(read, target_indel, qual_lim=23):
+    """could a realignment of this read show the target?  (localn.pyx:139-220: clipped at the locus, high-quality mismatches
+    or indels over the target's span; not when the read ends inside the target's repeat and matches the reference there)"""
+    if read["covering_subread"]:
+        is_covered = True
+        covering_start, covering_end = read["covering_subread"][0], read["covering_subread"][1]
+    else:
+        is_covered = False
+        if target_indel.is_ins:
+            return False
+        covering_start = target_indel.pos
+        covering_end = covering_start + len(target_indel.ref)
+    to_left, to_right = target_indel.pos - read["aln_start"], read["aln_end"] - target_indel.pos
+    is_lefty = True if to_left < 0 else False if to_right < 0 else to_left <= to_right
+    start_cigar, end_cigar = read["cigar_list"][0], read["cigar_list"][-1]
+    if is_lefty and covering_start < read["aln_start"] <= covering_end and int(start_cigar[:-1]) > 2:
+        return True
+    if not is_lefty and covering_start <= read["aln_end"] < covering_end and int(end_cigar[:-1]) > 2:
+        return True
+    mismatches = [m for m in read["mismatches"] if covering_start <= m[0] <= covering_end and m[3] > qual_lim]
+    shiftable = [v.pos for v in target_indel.generate_equivalents()]
+    lt_pos, rt_pos = min(shiftable), max(shiftable)
+    if lt_pos < rt_pos:
+        if is_lefty:
+            if lt_pos < read["aln_start"]:
+                k = rt_pos - read["aln_start"]
+                if read["read_seq"][:k] == read["ref_seq"][:k]:
+                    return False
+        elif read["aln_end"] <= rt_pos:
+            k = read["aln_end"] - lt_pos
+            if read["read_seq"][-k:] == read["ref_seq"][-k:]:
+                return False
+    if mismatches:
+        if is_lefty:
+            at_end = abs(min(m[0] for m in mismatches) - read["aln_start"]) < 4
+        else:
+            at_end = abs(max(m[0] for m in mismatches) - read["aln_end"]) < 4
+        return True if at_end else is_covered
+    return bool([v for v in read["I"] + read["D"] if covering_start <= v[0] <= covering_end])
+
+
+def _needs_realn(read, target_indel, mapq_lim):
+    """the filters of is_target_by_ssw that do not depend on the alignments (localn.pyx:243-249): None = already a target (left
+    as it is), False = not realigned (is_target set False), True = realign"""
+    if read["is_target"]:
+        return None
+    if read["is_reference_seq"] or read["mapq"] <= mapq_lim or not is_worth_realn(read, target_indel):
+        return False
+    return True
+
+
+def is_target_by_ssw(read, target_indel, contig, mut_ref_lt, mut_ref_mid, mut_ref_rt, mut_aligner, ref_aligner, match_score,
+                     mismatch_penalty, gap_open_penalty, gap_extension_penalty, indel_type, basequalthresh, mapq_lim,
+                     mapped_base_cnt_thresh=40, allow_mismatches=10):
+    """one read, the reference's signature (localn.pyx:223-291): two single alignments through the aligner objects.  The batched
+    form is find_by_smith_waterman_realn below; this one exists for callers that hold a single read."""
+    need = _needs_realn(read, target_indel, mapq_lim)
+    if need is None:
+        return read
+    if not need:
+        read["is_target"] = False
+        return read
+    read_seq = read["read_seq"]
+    ref_aln = align(ref_aligner, read_seq, gap_open_penalty, gap_extension_penalty)
+    mut_aln = align(mut_aligner, read_seq, len(read_seq), gap_extension_penalty)
+    return _apply_ssw_verdict(read, target_indel, mut_ref_lt, mut_ref_mid, mut_ref_rt, ref_aln, mut_aln)
+
+
+def _apply_ssw_verdict(read, target_indel, mut_ref_lt, mut_ref_mid, mut_ref_rt, ref_aln, mut_aln):
+    """localn.pyx:257-291 with the two alignments made"""
+    if mut_aln.optimal_score <= ref_aln.optimal_score:
+        read["is_target"] = False
+        return read
+    seq = read["read_seq"]
+    v = is_covering_target(read["read_name"], seq, target_indel.indel_seq, mut_ref_lt, mut_ref_mid, mut_ref_rt, mut_aln.CIGAR, len(seq),
+                           mut_aln.reference_start, mut_aln.reference_end, mut_aln.read_start, mut_aln.read_end,
+                           target_indel.count_repeats())
+    if v == 1:
+        read["is_target"] = True
+    elif v == -1:
+        read["undetermined"] = True
+    return read
+
+
+def find_by_smith_waterman_realn(target_indel, contig, pileup, match_score, mismatch_penalty, gap_open_penalty, gap_extension_penalty,
+                                 basequalthresh, mapq_lim=1, device=0):
+    """localn.pyx:15-68, same arguments, same annotated pileup back: every read that passes the filters is aligned to the
+    reference contig under (gap_open, gap_ext) and to the mutant contig with gap_open = len(read), all in ONE GPU batch, and
+    gets is_target / undetermined as is_target_by_ssw would have set them.  `contig` needs get_contig_seq(split=True) and
+    get_reference_seq() (contig.pyx)."""
+    mut_ref_lt, mut_ref_mid, mut_ref_rt = contig.get_contig_seq(split=True)
+    ref_ref = contig.get_reference_seq()
+    pileup = [findall_mismatches(read) for read in pileup]
+    todo = []
+    for k, read in enumerate(pileup):
+        need = _needs_realn(read, target_indel, mapq_lim)
+        if need is False:
+            read["is_target"] = False
+        elif need:
+            todo.append(k)
+    if todo:
+        pairs = align_pileup([pileup[k]["read_seq"] for k in todo], mut_ref_lt + mut_ref_mid + mut_ref_rt, ref_ref, match_score,
+                             mismatch_penalty, gap_open_penalty, gap_extension_penalty, device)
+        for k, (ref_aln, mut_aln) in zip(todo, pairs):
+            _apply_ssw_verdict(pileup[k], target_indel, mut_ref_lt, mut_ref_mid, mut_ref_rt, ref_aln, mut_aln)
+    return pileup
+
+
+def parse_read_by_mut_aln(mut_aln, contig, read, indel_type):
+    """the read cut into left flank / indel / right flank along its alignment to the mutant contig (localn.pyx:475-539).
+    `contig` needs lt_consensus_seq, indel_seq, rt_consensus_seq."""
+    from .pileup import get_end_pos, split
+    lt_len, indel_len = len(contig.lt_consensus_seq), len(contig.indel_seq)
+    read_seq, read_qual = read["read_seq"], read["read_qual"]
+    ref_start, ref_end = mut_aln.reference_start, mut_aln.reference_end
+    aln_start, aln_end = mut_aln.read_start, mut_aln.read_end
+    lt_flank = mid_seq = rt_flank = ""
+    lt_qual, rt_qual = [], []
+    if ref_start <= lt_len:
+        lt_diff = lt_len - ref_start
+        cut = aln_start + lt_diff
+        lt_flank, lt_qual = read_seq[aln_start:cut], read_qual[aln_start:cut]
+        if indel_type == "I":
+            mid_seq = read_seq[cut:min(cut + indel_len, aln_end)]
+        else:
+            rt_flank, rt_qual = read_seq[cut:], read_qual[cut:]
+            del_pos = get_end_pos(read["read_start"] + aln_start, lt_flank, read["cigar_string"])
+            _, rt_ref = split(read["ref_seq"], read["cigar_string"], del_pos, read["aln_start"], is_for_ref=True, reverse=False)
+            read["del_pos"] = del_pos
+            read["del_seq"] = rt_ref[:indel_len]
+    if lt_len + indel_len <= ref_end and indel_type == "I":
+        rt_diff = ref_end - (lt_len + indel_len)
+        rt_flank, rt_qual = read_seq[aln_end - rt_diff:aln_end], read_qual[aln_end - rt_diff:aln_end]
+        mid_seq = read_seq[max(aln_start, aln_end - rt_diff - indel_len):aln_end - rt_diff]
+    read["lt_flank"], read["lt_qual"], read["indel_seq"], read["rt_flank"], read["rt_qual"] = lt_flank, lt_qual, mid_seq, rt_flank, rt_qual
+    return read

@@ -460,3 +460,241 @@ def make_pileup(target, bam, unspl_loc_ref, exclude_duplicates, window, downsamp
             sample_factor = n_reads / len(segs)
     pileup = [dictize_read(s, chrom, pos, rpos, reference, unspl_loc_ref, basequalthresh) for s in segs]
     return [r for r in pileup if not is_within_intron(r, pos, window)], sample_factor
+
+
+# =====================================================================================================================
+# retarget / update_read_info / the overhang filter with the reference's signatures (pileup.pyx:495-913), composed from the
+# pieces above and in retarget.py.  The alignments are batched: retarget_many() runs the read pre-filter, the per-read
+# windows, every alignment of every (gap_open, gap_ext) pair still in play as ONE GPU call per recursion level (the
+# reference's window / 3 recursion for insertions, pileup.pyx:715-730 and 795-808, becomes one more batch per level, not one
+# more call per read), and the candidate selection (equivalents, difflib best match, `within`, complex reduction,
+# pileup.pyx:732-793).  retarget() is the one-pair case.  Parity: pinned by vectors from the reference's own function text
+# (oracle/gen_driver_golden.py).
+# =====================================================================================================================
+from difflib import SequenceMatcher, get_close_matches
+
+
+def _retarget_reads(target, pileup, mapq4retarget):
+    """the reads retarget realigns (pileup.pyx:592-634)"""
+    if target.is_ins:
+        non_refs = [r for r in pileup if not r["is_reference_seq"] and r["is_covering"] and r["mapq"] > mapq4retarget]
+    else:
+        non_refs = [r for r in pileup if not r["is_reference_seq"] and r["mapq"] > mapq4retarget]
+    if not non_refs:
+        return non_refs
+    clean = [r for r in non_refs if r["low_qual_base_num"] < 6 and not r["is_dirty"] and not r["is_end_dirty"] and r.get("is_worth_realn", True)]
+    return clean if clean else [r for r in non_refs if not r["is_dirty"]]
+
+
+def _retarget_select(target, non_refs, alns, ref_seqs, ref_starts, make, window, within, retargetcutoff, require_exact_for_shiftable):
+    """everything retarget does AFTER its alignments (pileup.pyx:650-808).  Returns ("done", result-or-None) or
+    ("shrink", window // 3): the reference's recursion with a smaller window.  make(ref_seq) builds the aligner object the
+    reference hands back per candidate read (only the reads of the final answer get one)."""
+    from .variant import Variant
+    target_type = target.variant_type
+    cutoff = 1.0 if len(target.indel_seq) < 3 else retargetcutoff
+    complex_flags, cand, cand_reads, cand_refs, cand_starts = [], [], [], [], []
+    for read, aln, ref_seq, ref_start in zip(non_refs, alns, ref_seqs, ref_starts):
+        if not aln.CIGAR:
+            continue
+        seq = read["read_seq"]
+        aligned_frac = (aln.read_end - aln.read_start) / min(len(seq), window * 6)
+        gaps = aln.CIGAR.count("I") + aln.CIGAR.count("D")
+        if not (0 < gaps < 6 and aligned_frac > 0.7):
+            continue
+        indels = findall_indels(aln, ref_start + aln.reference_start, ref_seq, seq)
+        positions = [d["pos"] for d in indels]
+        complex_positions = set(p for p in positions if positions.count(p) == 2)
+        if complex_positions:
+            complex_flags.append(1)
+        end_thresh = max(len(seq) / 30, 3)
+        for d in indels:
+            if d["indel_type"] != target_type:
+                continue
+            if d["pos"] in complex_positions:
+                dl = [x for x in indels if x["pos"] == d["pos"] and x["indel_type"] == "D"][0]
+                ins = [x for x in indels if x["pos"] == d["pos"] and x["indel_type"] == "I"][0]
+                ref, alt = dl["lt_ref"][-1] + dl["del_seq"], ins["lt_ref"][-1] + ins["indel_seq"]
+            elif target_type == "I":
+                ref = d["lt_ref"][-1]
+                alt = ref + d["indel_seq"]
+            else:
+                alt = d["lt_ref"][-1]
+                ref = alt + d["del_seq"]
+            var = Variant(target.chrom, d["pos"], ref, alt, target.reference, skip_validation=True)
+            at_end = var.pos - read["read_start"] <= end_thresh or read["read_end"] - var.pos <= end_thresh
+            if at_end and not (var == target or (complex_positions and var.pos not in complex_positions)):
+                continue                                             # a non-target indel at a read end is not considered
+            cand.append(var); cand_reads.append(read); cand_refs.append(ref_seq); cand_starts.append(ref_start)
+    shrink = ("shrink", int(window / 3)) if (target.is_ins and window > 3) else ("done", None)
+    if not cand:
+        return shrink                                                # (a long window may align an insertion as a deletion)
+    if len(target.indel_seq) <= 3 and not sum(complex_flags) and target not in cand:
+        return "done", None
+    u_cand = to_flat_list([v._generate_equivalents_private() for v in set(cand)])
+    u_cand.sort(key=lambda x: abs(x.pos - target.pos))
+    seqs = [v._get_indel_seq(how=target_type) for v in u_cand]
+    best = get_close_matches(target.indel_seq, seqs, n=1, cutoff=cutoff)
+    if not best:
+        return shrink
+    ratio = SequenceMatcher(None, target.indel_seq, best[0]).ratio()
+    hit = u_cand[seqs.index(best[0])]
+    if require_exact_for_shiftable and (len(hit.generate_equivalents()) > 1 or len(target.generate_equivalents()) > 1) and hit != target:
+        return "done", None
+    if not abs(target.pos - hit.pos) < within:
+        return "done", None
+    try:
+        k = cand.index(hit)                                          # the original representation: no normalisation here
+    except ValueError:
+        hit.pos = hit.pos - len(hit.ref)
+        k = cand.index(hit)
+    candidate = cand[k]
+    idx = [i for i, v in enumerate(cand) if v == candidate]
+    if candidate.is_non_complex_indel():                             # can it be the del / ins component of a complex indel?
+        for cplx in [v for v in set(cand) if not v.is_non_complex_indel()]:
+            reduced = cplx._reduce_complex_indel(to=target_type)
+            if candidate == reduced:
+                idx = [i for i, v in enumerate(cand) if v == cplx]
+                candidate = reduced
+                break
+    else:
+        candidate = candidate._reduce_complex_indel(to=target_type)
+    pick = lambda lst: [lst[i] for i in idx]
+    return "done", (candidate, pick(cand_reads), ratio, pick(cand_refs), pick(cand_starts), [make(w) for w in pick(cand_refs)])
+
+
+def retarget_many(target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty, gap_pairs, unspl_loc_ref,
+                  require_exact_for_shiftable, device=0):
+    """retarget (pileup.pyx:577-808) for every (gap_open, gap_ext) of gap_pairs at once.  Returns (results, alignments):
+    results[g] = what retarget(..., gap_pairs[g][0], gap_pairs[g][1], ...) returns (None, or the 6-tuple with SSW aligner
+    objects last); alignments[g] = {id(read): Alignment} of the level that produced results[g] (update_read_info makes the same
+    alignment again in the reference; the caller can reuse it)."""
+    from .localn import make_aligner
+    from .retarget import align_many, get_local_reference
+    non_refs = _retarget_reads(target, pileup, mapq4retarget)
+    results, used = [None] * len(gap_pairs), [{} for _ in gap_pairs]
+    if not non_refs:
+        return results, used
+    level = {g: window for g in range(len(gap_pairs))}               # pairs still searching -> their current window
+    while level:
+        geom = {}                                                    # window size -> (ref_seqs, ref_starts) of the reads
+        for w in set(level.values()):
+            refs, starts = [], []
+            for read in non_refs:
+                ref_seq, lt_len = get_local_reference(target, [read], w, unspl_loc_ref)
+                refs.append(ref_seq)
+                starts.append(target.pos + 1 - lt_len)
+            geom[w] = (refs, starts)
+        order = sorted(level)
+        R, W, GO, GE = [], [], [], []
+        for g in order:
+            refs = geom[level[g]][0]
+            for read, ref_seq in zip(non_refs, refs):
+                R.append(read["read_seq"]); W.append(ref_seq); GO.append(gap_pairs[g][0]); GE.append(gap_pairs[g][1])
+        alns = align_many(R, W, GO, GE, match_score, mismatch_penalty, device)
+        n = len(non_refs)
+        nxt = {}
+        for q, g in enumerate(order):
+            w = level[g]
+            refs, starts = geom[w]
+            mine = alns[q * n:(q + 1) * n]
+            make = lambda ref_seq: make_aligner(ref_seq, match_score, mismatch_penalty)
+            verdict, val = _retarget_select(target, non_refs, mine, refs, starts, make, w, within, retargetcutoff, require_exact_for_shiftable)
+            if verdict == "shrink":
+                nxt[g] = val
+            else:
+                results[g] = val
+                used[g] = {id(r): a for r, a in zip(non_refs, mine)}
+        level = nxt
+    return results, used
+
+
+def retarget(target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty, gap_open_penalty,
+             gap_extension_penalty, unspl_loc_ref, require_exact_for_shiftable, device=0):
+    """pileup.pyx:577-808, same arguments, same return value: None, or (candidate, candidate_reads, match ratio,
+    candidate_ref_seqs, candidate_ref_starts, candidate_aligners)"""
+    return retarget_many(target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty,
+                         [(gap_open_penalty, gap_extension_penalty)], unspl_loc_ref, require_exact_for_shiftable, device)[0][0]
+
+
+def update_read_info(read, candidate, is_gapped_aln=True, gap_open_penalty=3, gap_extension_penalty=1, aligner=None, ref_seq=None,
+                     ref_start=None, aln=None):
+    """pileup.pyx:811-913, same arguments (+ aln: the read's alignment when the caller already has it -- grid_search does).
+    Gapped branch: the read carries the candidate in its own CIGAR; realignment branch: see update_read_info_realn."""
+    if is_gapped_aln:
+        parsed = leftalign_indel_read(candidate.chrom, candidate.pos, len(candidate.indel_seq), candidate.variant_type, read["cigar_string"],
+                                      read["read_start"], read["aln_start"], read["read_seq"], read["ref_seq"], read["read_qual"],
+                                      candidate.reference)
+        read["lt_flank"] = parsed[1]
+        read["indel_seq"] = parsed[2] if candidate.is_ins else ""
+        read["rt_flank"], read["lt_ref"], read["rt_ref"], read["lt_qual"], read["rt_qual"] = parsed[3], parsed[4], parsed[5], parsed[6], parsed[7]
+        read["lt_cigar"], read["rt_cigar"] = split_cigar(read["cigar_string"], candidate.pos, read["read_start"])
+        read["is_target"] = True
+        return read
+    if aln is None:
+        from .localn import align
+        aln = align(aligner, read["read_seq"], gap_open_penalty, gap_extension_penalty)
+    from .variant import Variant
+    same = lambda pos, ref, alt: candidate == Variant(candidate.chrom, pos, ref, alt, candidate.reference, skip_validation=True)
+    return update_read_info_realn(read, aln, ref_seq, ref_start, candidate.pos, candidate.indel_seq, candidate.is_ins, same)
+
+
+def is_junctional(read):
+    return read["is_covering"] if read["intron_pattern"] == (0, 0) else True
+
+
+def check_overhangs(pileup, splice_rate=0.1):
+    """(intron, overhanging reads) when the locus sits at a well-supported exon boundary (pileup.pyx:427-451)"""
+    from .retarget import most_common
+    intron_ptrns = [r["intron_pattern"] for r in pileup if is_junctional(r)]
+    introns = [p for p in intron_ptrns if p != (0, 0)]
+    if not introns:
+        return None
+    intron = most_common(introns)
+    if intron_ptrns.count(intron) / len(intron_ptrns) < splice_rate:
+        return None
+    overhangs = [r for r in pileup if is_overhang(r, intron[0], intron[1])]
+    return (intron, overhangs) if overhangs else None
+
+
+def is_overhang(read, intron_start, intron_end):
+    """the covering piece of the read hangs over one edge of the intron (pileup.pyx:461-474)"""
+    sub = read["covering_subread"]
+    if not sub:
+        return False
+    lt, rt = max(sub[0], read["aln_start"]), min(sub[1], read["aln_end"])
+    return (lt < intron_start and rt < intron_end) or (intron_start < lt and intron_end < rt)
+
+
+def overhang_windows(target, intron):
+    """(genome window, exon-exon junction window) of overhang_aligners (pileup.pyx:477-492)"""
+    genome_ref = target.reference.fetch(target.chrom, target.pos - 100, target.pos + 100)
+    lt_exon_end, rt_exon_start = intron[0] - 1, intron[1]
+    junction_ref = target.reference.fetch(target.chrom, lt_exon_end - 100, lt_exon_end) + target.reference.fetch(target.chrom, rt_exon_start, rt_exon_start + 100)
+    return genome_ref, junction_ref
+
+
+def filter_spurious_overhangs(target, intron, overhangs, match_score, mismatch_penalty, gap_open_penalty, gap_extension_penalty, device=0):
+    """pileup.pyx:495-525 / 527-574, same arguments: the overhanging reads that are not spurious.  Both alignments of every
+    non-reference overhang are one GPU batch; the read-level checks follow per read as in the reference."""
+    from .localn import findall_mismatches, is_worth_realn
+    from .retarget import overhang_alignment_verdicts
+    genome_ref, junction_ref = overhang_windows(target, intron)
+    todo = [r for r in overhangs if not r["is_reference_seq"]]
+    verdicts, _ = overhang_alignment_verdicts([r["read_seq"] for r in todo], genome_ref, junction_ref, match_score, mismatch_penalty,
+                                              gap_open_penalty, gap_extension_penalty, device)
+    lt_exon_end, rt_exon_start = intron[0] - 1, intron[1]
+    out = []
+    for read, v in zip(todo, verdicts):
+        if v is False:
+            continue
+        # (the reference's expression: `read["D"] and read["I"]` is read["I"] when the read has deletions, else the empty list;
+        #  the list of booleans is only tested for being non-empty)
+        within = [lt_exon_end < var[-1].pos < rt_exon_start for var in (read["D"] and read["I"])]
+        if within:
+            out.append(read)
+            continue
+        findall_mismatches(read)
+        if is_worth_realn(read, target):
+            out.append(read)
+    return out

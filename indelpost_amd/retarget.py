@@ -244,3 +244,26 @@ def perfect_match_batch(read_seqs, contig_seq, match_score, mismatch_penalty, de
     for seq, a in zip(read_seqs, alignments_from(g.align(jobs))):
         out.append(contig_seq[a.reference_start:a.reference_end] == seq[a.read_start:a.read_end])
     return out
+
+
+def align_many(read_seqs, ref_seqs, gap_opens, gap_exts, match_score, mismatch_penalty, device=0):
+    """One GPU batch of arbitrary (read, window, gap_open, gap_ext) jobs -> Alignment tuples in job order.  Reads and windows
+    that repeat (the same read under several penalty pairs, reads sharing a window) are stored once per distinct window."""
+    n = len(read_seqs)
+    if n == 0:
+        return []
+    raw = [s.encode("utf8") if isinstance(s, str) else bytes(s) for s in read_seqs]
+    lens = np.fromiter((len(b) for b in raw), np.int64, n)
+    reads = encode_dna(b"".join(raw))
+    read_off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=read_off[1:])
+    uniq, wid = {}, np.empty(n, np.int32)
+    for k, w in enumerate(ref_seqs):
+        wid[k] = uniq.setdefault(w, len(uniq))
+    wins = [encode_dna(w) for w in uniq]
+    ref_off = np.zeros(len(wins) + 1, np.int64)
+    np.cumsum([len(w) for w in wins], out=ref_off[1:])
+    refs = np.concatenate(wins) if ref_off[-1] else np.zeros(0, np.int8)
+    g = _gpu(device)
+    g.set_scoring(matrix=dna_score_matrix(match_score, mismatch_penalty), flag=1, score_size=2)
+    return alignments_from(g.align(JobTable(reads, read_off, refs, ref_off, wid, np.asarray(gap_opens, np.int64), np.asarray(gap_exts, np.int64))))

@@ -1,0 +1,53 @@
+"""The composed drivers above the aligner (retarget / grid_search / update_read_info, the overhang filter,
+find_by_smith_waterman_realn, the pileup front-end) against vectors produced by the reference's own function text
+(oracle/gen_driver_golden.py -> tests/golden/driver_cases.json).  CPU: the host code is the package's, the alignments come
+from the oracle through the GpuAligner interface (tests/port_backend.py); tests/test_gpu_driver.py replays the same vectors
+through libindelpost_hip.so."""
+import pytest
+
+from tests import driver_replay as DR
+
+
+@pytest.fixture()
+def port_as_gpu(oracle_mod, monkeypatch):
+    from indelpost_amd import localn, retarget, sswpy
+    from tests.port_backend import PortAligner
+    cache = {}
+
+    def fake(device=0):
+        if device not in cache:
+            cache[device] = PortAligner(oracle_mod, device)
+        return cache[device]
+    for m in (sswpy, localn, retarget):
+        monkeypatch.setattr(m, "_gpu", fake)
+    return cache
+
+
+@pytest.fixture(scope="module")
+def cases():
+    return DR.load()
+
+
+def test_pileup_front_end_matches_the_reference(cases, port_as_gpu):
+    """make_pileup / fetch_reads / dictize_read / get_ref_seq / get_local_reference (spliced and unspliced): every read dict,
+    field by field (bulky fields by digest), and every per-read window"""
+    n = sum(DR.replay(sc, cases["genomes"], parts=("pileup", "local_reference")) for sc in cases["scenarios"])
+    assert n > 2500
+
+
+def test_retarget_and_grid_search_match_the_reference(cases, port_as_gpu):
+    """retarget under single penalty pairs (hits, misses, decoys, the window / 3 recursion) and the whole grid search with
+    update_read_info on the winning reads: candidate, reads, gap penalties, every updated read dict"""
+    n = 0
+    for sc in cases["scenarios"]:
+        n += DR.replay(sc, cases["genomes"], parts=("retarget", "grid_search"))
+    assert n == sum(len(sc["retarget"]) + 1 for sc in cases["scenarios"])
+    g = port_as_gpu[0]
+    # the batching claim: one call per recursion level of a retarget / grid search, not one per read or per penalty pair
+    assert g.n_calls < 1.5 * n and g.n_jobs > 10 * g.n_calls
+
+
+def test_overhang_filter_and_smith_waterman_realn_match_the_reference(cases, port_as_gpu):
+    n = sum(DR.replay(sc, cases["genomes"], parts=("overhangs", "realn", "parse", "perfect")) for sc in cases["scenarios"])
+    assert n > 1000
+    assert sum(1 for sc in cases["scenarios"] if sc["overhangs"]) >= 4

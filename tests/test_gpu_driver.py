@@ -223,3 +223,14 @@ def test_gpu_bam_locus_to_target_reads(gpu, oracle_mod, port, tmp_path):
                                 _oracle_alignment(oracle_mod, port, r, lt + rt, mat, len(r), 1)), k
     found = {pile[k]["read_name"] for k in np.flatnonzero(is_t)}
     assert found == {n for n in hidden if n in {r["read_name"] for r in pile}} and not und.any()
+
+
+def test_gpu_composed_drivers_replay_reference_vectors():
+    """retarget / grid_search / update_read_info, the overhang filter, find_by_smith_waterman_realn and the pileup front-end as
+    ONE stack on the GPU: the vectors of tests/golden/driver_cases.json (the reference's own function text, run against duck-typed
+    BAM / FASTA with the oracle as aligner: oracle/gen_driver_golden.py) replayed through libindelpost_hip.so -- whole return
+    values and whole read dicts compared."""
+    from tests import driver_replay as DR
+    cases = DR.load()
+    n = sum(DR.replay(sc, cases["genomes"]) for sc in cases["scenarios"])
+    assert n > 4000
