@@ -43,38 +43,102 @@ def run_end_to_end(ip, jobs, scoring, dev, streams, steps, depth=None):
             g.close()
 
 
+def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
+    """The many-loci entry (indelpost_amd.align_loci) on the config-5 shape: `n_loci` loci, each its own JobTable of 16 reads x 6
+    gap-penalty pairs with per-read windows (what retarget_jobs builds per locus), handed over as a LIST per step.  Timed per
+    step: JobTable.concat + upload + pipeline + download + BatchResult.split -- host memory to host memory, everything a caller
+    of grid_search_many pays below its own Python."""
+    from indelpost_amd import synth
+    from indelpost_amd.batch import JobTable, align_loci
+    jobs = synth.config5_jobs(n_loci=n_loci)
+    per = jobs.n_jobs // n_loci
+    loci = [jobs.shard(k * per, (k + 1) * per) for k in range(n_loci)]          # outside the timed region: the caller's own tables
+    g = ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams)
+    try:
+        for _ in range(2):
+            parts = align_loci(loci, aligner=g)
+        t_cat = t_all = 0.0
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            table = JobTable.concat(loci)
+            t1 = time.perf_counter()
+            parts = g.align(table).split([t.n_jobs for t in loci])
+            t2 = time.perf_counter()
+            t_cat += t1 - t0
+            t_all += t2 - t0
+        whole = ip.BatchResult(np.concatenate([p.records for p in parts]), parts[0].cigar_pool)
+        dt = t_all / steps
+        return {"value": round(jobs.n_jobs / dt / 1e6, 4), "unit": "million alignments/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+                "n_loci": n_loci, "jobs_per_locus": per, "n_jobs": jobs.n_jobs, "concat_ms_per_step": round(t_cat / steps * 1e3, 3),
+                "digest": whole.digest(), "sum_score1": int(whole.records["score1"].astype(np.int64).sum()),
+                "note": "host memory to host memory through align_loci (concat + H2D + pipeline + D2H + split); compare with configs.5, "
+                        "the same jobs resident in HBM"}
+    finally:
+        g.close()
+
+
+def config4_chunk(rank, windows_per_gpu=1250):
+    """chunk `rank` of the config-4 table: BASELINE configs[3] is 10 M reads over 8 GPUs = 1250 windows x 996 reads per GPU; every
+    rank generates only its own chunk (its own generator seed), so the table of an N-GPU run is N chunks = N x 1.245 M jobs"""
+    from indelpost_amd import synth
+    return synth.config4_jobs(n_windows=windows_per_gpu, seed=synth.SEED + 977 * rank)
+
+
+def gather_bytes(dist, rank, world, arrays):
+    """rank 0 receives every rank's arrays (uint8 views) through dist.gather of padded uint8 tensors -- no pickling; returns, on rank
+    0, a list (per rank) of lists of numpy uint8 arrays"""
+    import torch
+    sizes = torch.tensor([a.nbytes for a in arrays], dtype=torch.int64)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    out = [[] for _ in range(world)]
+    for q, a in enumerate(arrays):
+        cap = int(max(int(s_[q]) for s_ in all_sizes))
+        buf = torch.zeros(max(cap, 1), dtype=torch.uint8)
+        if a.nbytes:
+            buf[:a.nbytes] = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        got = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, got, dst=0)
+        if rank == 0:
+            for r in range(world):
+                out[r].append(got[r][:int(all_sizes[r][q])].numpy())
+    return out if rank == 0 else None
+
+
 def run_sharded(ip, args, dist, rank, world, my_devices, aligner_cls):
-    """strong-scaling form: the table is fixed, the ranks split it"""
-    from bench import WORKLOADS, make_jobs, check_results
-    from indelpost_amd.batch import BatchResult, merge_results, shard_bounds
+    """BASELINE configs[3]: the config-4 table sharded over the GPUs -- 1250 windows (1.245 M jobs) per GPU, 10 M at 8 GPUs.  Every
+    rank generates the chunk it owns, cuts it over its streams by WORK (shard_bounds with the table), uploads, runs, downloads, and
+    rank 0 gathers every record and CIGAR inside the timed region (dist.gather of uint8 tensors; no data-path collective on the
+    GPUs).  value = all jobs of all ranks / max-over-ranks time: weak scaling in the table's own terms."""
+    from bench import WORKLOADS, check_results
+    from indelpost_amd.batch import BatchResult, merge_results
     from indelpost_amd._lib import RESULT_DTYPE
     name = "4"
     scoring, desc = WORKLOADS[name]
-    jobs = make_jobs(name, args.reads_per_gpu)                   # every rank generates the same table (deterministic)
-    if args.backend == "emu":                                    # CPU rehearsal: a few jobs are enough
-        jobs = jobs.shard(0, 48)
     n_parts = world if world > 1 else len(my_devices)
-    b = shard_bounds(jobs.n_jobs, n_parts)
     mine = [rank] if world > 1 else list(range(n_parts))
+    wpg = int(os.environ.get("IPX_SHARDED_WINDOWS_PER_GPU", "1250"))
+    chunks = {k: config4_chunk(k, wpg) for k in mine}
+    if args.backend == "emu":                                    # CPU rehearsal: a few jobs are enough
+        chunks = {k: c.shard(0, 48) for k, c in chunks.items()}
     aligners = [ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=args.streams, aligner_cls=aligner_cls)
                 for dev in my_devices]
+    for g in aligners:
+        g.balance_by_cells = True                                # stream slices of near-equal work, not near-equal job count
 
     def step():
         parts = {}
-        shards = {k: jobs.shard(b[k], b[k + 1]) for k in mine}   # host packing is part of the job
         for g, k in zip(aligners, mine):
-            g.upload(shards[k])
+            g.upload(chunks[k])
             g.run()
         for g, k in zip(aligners, mine):
             g.sync()
             parts[k] = g.download()
         if dist is not None:                                     # host-side gather on rank 0 (no data-path collective on the GPUs)
-            payload = (parts[rank].records.tobytes(), np.ascontiguousarray(parts[rank].cigar_pool).tobytes())
-            gathered = [None] * world if rank == 0 else None
-            dist.gather_object(payload, gathered, dst=0)
+            got = gather_bytes(dist, rank, world, [parts[rank].records.view(np.uint8).reshape(-1), np.ascontiguousarray(parts[rank].cigar_pool).view(np.uint8)])
             if rank != 0:
                 return None
-            ordered = [BatchResult(np.frombuffer(r, RESULT_DTYPE), np.frombuffer(p, np.uint32)) for r, p in gathered]
+            ordered = [BatchResult(r.view(RESULT_DTYPE), p.view(np.uint32)) for r, p in got]
         else:
             ordered = [parts[k] for k in range(n_parts)]
         return merge_results(ordered)
@@ -97,16 +161,21 @@ def run_sharded(ip, args, dist, rank, world, my_devices, aligner_cls):
     for g in aligners:
         g.close()
     if rank == 0:
-        chk = check_results(name, res, jobs, 0 if args.backend == "hip" else 1)
+        jobs_total = len(res.records)
+        chunk0 = chunks[0]
+        first = BatchResult(res.records[:chunk0.n_jobs], res.cigar_pool)           # chunk 0 is the 1250-window table of seed 0
+        chk = check_results("4x1250", first, chunk0, 0 if args.backend == "hip" else 1)
         out = {"metric": "million read-alignments/sec (150 bp x 300 bp, affine gap)", "mode": "sharded",
-               "value": round(jobs.n_jobs * args.steps / elapsed / 1e6, 6), "unit": "million alignments/s",
+               "value": round(jobs_total * args.steps / elapsed / 1e6, 6), "unit": "million alignments/s",
                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "int16 (packed pairs; the 8-bit pass is computed in 16-bit containers)",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None,
+               "dtype": "f16 (16-bit passes and the plain 8-bit recurrence: packed halves, exact for these integers) / int16 (stepped 8-bit passes)",
                "data": "synthetic",
-               "config": {"workload": desc.format(n=jobs.n_jobs) + "; ONE table sharded over the ranks (JobTable.shard), "
-                                      "upload + run + download per shard and the host gather on rank 0 inside the timed region",
-                          "jobs_total": jobs.n_jobs, "streams_per_gpu": args.streams, "backend": args.backend}}
+               "config": {"workload": "config4: %d reads of 75/100/125/150/200/250 bp vs windows of 200-600 bp (one window per 996 reads), "
+                                      "(3,2,3,1), %d windows per GPU; every rank generates and aligns its chunk (upload + run + download) and "
+                                      "rank 0 gathers every record and CIGAR inside the timed region" % (jobs_total, wpg),
+                          "jobs_total": jobs_total, "jobs_per_gpu": jobs_total // max(1, n_parts), "streams_per_gpu": args.streams, "backend": args.backend}}
         out.update(chk)
         print(json.dumps(out))
     if dist is not None:

@@ -177,6 +177,9 @@ int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out9);   /* traceback routing of t
  * (no terminators); off[i]..off[i+1] delimits job i (empty for a job without CIGAR), off has n+1 entries.
  * Returns the total length, or -(needed length) when `cap` is too small (nothing is written then). */
 int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, char *out, int64_t cap, int64_t *off);
+/* host-side helper: FNV-1a (32 bit) of every job's BAM-encoded CIGAR ops, 2166136261 for a job without CIGAR (whole batches are
+ * compared op for op with the reference through these, and record digests are built on them) */
+void ipx_cigar_hashes(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, uint32_t *out);
 
 /* deterministic synthetic workload of SURVEY.md section 8d (xorshift64), host side:
  * one window of `wl` codes and n reads of `rl` codes; returns the final generator state */

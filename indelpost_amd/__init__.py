@@ -20,7 +20,12 @@ __version__ = "0.1.0"
 
 from .variant import Variant, NullVariant                                   # noqa: F401,E402
 from . import bamio                                                         # noqa: F401,E402
-from .pileup import make_pileup, dictize_read, fetch_reads, parse_spliced_read   # noqa: F401,E402
+from .pileup import (make_pileup, dictize_read, fetch_reads, parse_spliced_read, retarget_many, update_read_info,   # noqa: F401,E402
+                     check_overhangs, filter_spurious_overhangs)
+from .localn import (find_by_smith_waterman_realn, find_by_smith_waterman_realn_many, is_target_by_ssw, is_worth_realn,   # noqa: F401,E402
+                     findall_mismatches, parse_read_by_mut_aln)
+from .varaln import grid_search, grid_search_many, is_perfect_match                                                       # noqa: F401,E402
+# (retarget itself lives where the reference has it: indelpost_amd.pileup.retarget -- the name indelpost_amd.retarget is the module)
 
 _WHY = ("%s (%s) is outside the hot path this package replaces (SURVEY.md section 8: contig / consensus construction, "
         "phasing, the orchestration state machine); use the reference implementation for it and plug this package in at "

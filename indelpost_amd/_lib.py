@@ -37,7 +37,7 @@ EXPORTS = [
     "ipx_run", "ipx_sync", "ipx_download", "ipx_download_async", "ipx_wait", "ipx_set_async_io", "ipx_pin_host",
     "ipx_unpin_host", "ipx_align_batch", "ipx_set_profiling",
     "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts",
-    "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars",
+    "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars", "ipx_cigar_hashes",
 ]
 
 
@@ -58,7 +58,8 @@ def needs_build():
 
 def build(force=False, verbose=False, jobs=None):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU): one object per translation unit,
-    in parallel, then one link."""
+    in parallel, then one link.  Safe under torchrun, where every rank may find the library stale at once: the build is
+    serialised by a file lock, objects and the library are written under temporary names and renamed into place."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -67,32 +68,47 @@ def build(force=False, verbose=False, jobs=None):
             return LIB_PATH          # prebuilt library travelled with the tree
         raise IpxError("hipcc not found and %s is not built" % LIB_PATH)
     os.makedirs(BUILD_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(BUILD_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():                    # another process built it while we waited
+                return LIB_PATH
+            return _build_locked(hipcc, force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(hipcc, force, verbose, jobs):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    tag = ".tmp%d" % os.getpid()
     objs, todo = [], []
     for src in UNITS:
         obj = os.path.join(BUILD_DIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            todo.append([hipcc] + flags + ["-c", src, "-o", obj])
+            todo.append((obj, [hipcc] + flags + ["-c", src, "-o", obj + tag]))
     jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 2)))
-    running = []
-    for cmd in todo:
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        running.append((cmd, subprocess.Popen(cmd)))
-        while len([p for _, p in running if p.poll() is None]) >= jobs:
-            running[0][1].wait() if running[0][1].poll() is None else None
-            for _, p in running:
-                if p.poll() is None:
-                    p.wait()
-                    break
-    for cmd, p in running:
+    running, pending = [], list(todo)
+    failed = None
+    while pending or running:
+        while pending and len(running) < jobs:
+            obj, cmd = pending.pop(0)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((obj, cmd, subprocess.Popen(cmd)))
+        obj, cmd, p = running.pop(0)
         if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+            failed = failed or subprocess.CalledProcessError(p.returncode, cmd)
+        else:
+            os.replace(obj + tag, obj)
+    if failed:
+        raise failed
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
+    os.replace(LIB_PATH + tag, LIB_PATH)
     return LIB_PATH
 
 
@@ -143,6 +159,8 @@ def lib():
     L.ipx_synth_window.argtypes = [C.c_uint64, vp, i32]
     L.ipx_format_cigars.restype = C.c_int64
     L.ipx_format_cigars.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.ipx_cigar_hashes.restype = None
+    L.ipx_cigar_hashes.argtypes = [vp, vp, i64, vp]
     L.ipx_synth_reads.restype = C.c_uint64
     L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
     L.ipx_synth_mixed.restype = i64

@@ -98,6 +98,29 @@ class JobTable:
         fc = np.concatenate(f) if f and fo[-1] else np.zeros(0, np.int8)
         return cls(rc, ro, fc, fo, ref_id, gap_open, gap_ext)
 
+    @classmethod
+    def concat(cls, tables):
+        """Many job tables as ONE (the many-loci entry: a locus' few hundred jobs are far too few to fill a GPU, a thousand loci are
+        not): jobs in table order, windows renumbered.  Per table only list appends; the offsets are fixed up with one vectorised
+        add per field, so ten thousand loci cost milliseconds.  mask_len: kept when every table has it, else the default rule."""
+        tables = list(tables)
+        if not tables:
+            return cls(np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int32), 0, 0)
+        nj = np.fromiter((t.n_jobs for t in tables), np.int64, len(tables))
+        nr = np.fromiter((t.n_refs for t in tables), np.int64, len(tables))
+        rbytes = np.fromiter((int(t.read_off[-1]) for t in tables), np.int64, len(tables))
+        fbytes = np.fromiter((int(t.ref_off[-1]) for t in tables), np.int64, len(tables))
+        rbase, fbase, wbase = np.cumsum(rbytes) - rbytes, np.cumsum(fbytes) - fbytes, np.cumsum(nr) - nr
+        read_off = np.zeros(int(nj.sum()) + 1, np.int64)
+        read_off[1:] = np.concatenate([t.read_off[1:] for t in tables]) + np.repeat(rbase, nj)
+        ref_off = np.zeros(int(nr.sum()) + 1, np.int64)
+        ref_off[1:] = np.concatenate([t.ref_off[1:] for t in tables]) + np.repeat(fbase, nr)
+        ref_id = np.concatenate([t.ref_id for t in tables]) + np.repeat(wbase, nj).astype(np.int32)
+        masks = [t.mask_len for t in tables]
+        mask = np.concatenate(masks) if all(m is not None for m in masks) else None
+        return cls(np.concatenate([t.reads[:t.read_off[-1]] for t in tables]), read_off, np.concatenate([t.refs[:t.ref_off[-1]] for t in tables]),
+                   ref_off, ref_id, np.concatenate([t.gap_open for t in tables]), np.concatenate([t.gap_ext for t in tables]), mask)
+
     def shard(self, lo, hi):
         """Contiguous job range [lo, hi) with only the windows it references."""
         rid = self.ref_id[lo:hi]
@@ -129,19 +152,18 @@ class JobTable:
                         self.gap_ext[lo:hi], mask)
 
 
-def record_digest(rec, wsum):
-    """Order-sensitive 64-bit digest of a batch's results: every field of every record plus, per job, the weighted
-    sum of its BAM-encoded CIGAR ops  wsum[i] = sum_q cigar[q]*(q+1) mod 2^32.  bench.py compares it with the digest
-    of the reference's results on the same job table (tests/golden/bench_digests.json)."""
+def record_digest(rec, cigar_hash):
+    """64-bit digest (xxHash64) of a batch's results in job order: every public field of every record -- score1, score2, the five
+    coordinates, flag, cigar_len -- and, per job, the FNV-1a hash of its BAM-encoded CIGAR ops.  bench.py compares it with the
+    digest of the reference's results on the same job table (tests/golden/bench_digests.json, oracle/gen_bench_digests.py).
+    (r02 used a position-weighted sum; a real hash cannot cancel.)"""
+    import xxhash
     n = len(rec)
-    u = lambda a: np.asarray(a).astype(np.int64).astype(np.uint64)
-    with np.errstate(over="ignore"):
-        mix = (u(rec["score1"]) + np.uint64(3) * u(rec["score2"]) + np.uint64(5) * u(rec["ref_begin1"].astype(np.int64) + 2)
-               + np.uint64(7) * u(rec["ref_end1"].astype(np.int64) + 2) + np.uint64(11) * u(rec["read_begin1"].astype(np.int64) + 2)
-               + np.uint64(13) * u(rec["read_end1"].astype(np.int64) + 2) + np.uint64(17) * u(rec["ref_end2"].astype(np.int64) + 2)
-               + np.uint64(19) * u(rec["flag"]) + np.uint64(23) * u(rec["cigar_len"]) + np.uint64(31) * u(wsum))
-        w = np.arange(1, n + 1, dtype=np.uint64)
-        return int((mix * w).sum(dtype=np.uint64))
+    m = np.empty((n, 10), np.int64)
+    for k, f in enumerate(("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2", "flag", "cigar_len")):
+        m[:, k] = rec[f]
+    m[:, 9] = np.asarray(cigar_hash, np.uint32)
+    return xxhash.xxh64(np.ascontiguousarray(m, "<i8").tobytes()).intdigest()
 
 
 class BatchResult:
@@ -153,6 +175,19 @@ class BatchResult:
 
     def __len__(self):
         return len(self.records)
+
+    def copy(self):
+        """a result that owns its arrays (results collected into pinned buffers are views that a later collect() overwrites)"""
+        return BatchResult(self.records.copy(), np.array(self.cigar_pool, np.uint32, copy=True))
+
+    def split(self, counts):
+        """the results of a concatenated job table (JobTable.concat) back as one BatchResult per table: record views that share
+        the cigar pool (cigar_off stays an index into it)"""
+        out, at = [], 0
+        for n in counts:
+            out.append(BatchResult(self.records[at:at + int(n)], self.cigar_pool))
+            at += int(n)
+        return out
 
     def cigar_ops(self, i):
         r = self.records[i]
@@ -200,8 +235,19 @@ class BatchResult:
         return (np.bincount(idx, weights=(ops * (within + 1)).astype(np.float64), minlength=n).astype(np.uint64)
                 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
 
+    def cigar_hashes(self):
+        """per job: FNV-1a (32 bit) of its BAM-encoded CIGAR ops, 2166136261 without a CIGAR (one call into the library)"""
+        from . import _lib
+        n = len(self.records)
+        out = np.zeros(n, np.uint32)
+        if n:
+            rec = np.ascontiguousarray(self.records)
+            pool = np.ascontiguousarray(self.cigar_pool, np.uint32)
+            _lib.lib().ipx_cigar_hashes(rec.ctypes.data, pool.ctypes.data if pool.size else None, n, out.ctypes.data)
+        return out
+
     def digest(self):
-        return record_digest(self.records, self.cigar_wsums())
+        return record_digest(self.records, self.cigar_hashes())
 
     def as_dict(self, i):
         """Same keys as oracle.Backend.align() for direct comparison in tests."""
@@ -259,11 +305,13 @@ class GpuAligner:
 
     # -- staged interface (bench.py: inputs resident in HBM before the timed region) --
     def upload(self, jobs):
-        self._jobs = jobs   # keep host arrays alive
-        self._n_jobs = jobs.n_jobs
+        # The previous table stays referenced until ipx_upload returns: in asynchronous mode its H2D copies may still be in flight
+        # and the library waits for them first thing; only then may its arrays (and the temporaries JobTable.shard made) go.
         self._check(self._L.ipx_upload(self._ctx, _p(jobs.reads), _p(jobs.read_off), _p(jobs.refs), _p(jobs.ref_off),
                                        _p(jobs.ref_id), _p(jobs.gap_open), _p(jobs.gap_ext), _p(jobs.mask_len),
                                        jobs.n_jobs, jobs.n_refs), "ipx_upload")
+        self._jobs = jobs   # keep host arrays alive
+        self._n_jobs = jobs.n_jobs
 
     def run(self):
         self._check(self._L.ipx_run(self._ctx), "ipx_run")
@@ -391,28 +439,47 @@ class MultiStreamAligner:
         cls = GpuAligner if aligner_cls is None else aligner_cls
         self.parts = [cls(device, match_score, mismatch_penalty, matrix) for _ in range(max(1, streams))]
         self.min_jobs_per_stream = 50000
+        self.balance_by_cells = False   # cut the stream slices by work (read length x window length) instead of by job count
         self._active = self.parts
         self._pinned = []            # host arrays page-locked by pin_host (kept alive here)
-        self._out = None             # (records, cigar pool) reused across align() calls when pinned
+        self._out = None             # pinned (records, cigar pool) pairs, used in alternation by collect(): see pin_host
+        self._out_turn = 0
 
     def close(self):
         self.unpin()
         for p in self.parts:
             p.close()
 
+    def __del__(self):                 # (an aligner dropped without close() must not leave page-locked arrays behind)
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # -- page-locked host buffers: transfers that overlap the other slices' kernels --
     def pin_host(self, jobs, cigar_ops_per_job=16):
         """Page-lock the arrays of `jobs` and a reusable pair of output buffers (hipHostRegister) and switch the contexts to
         asynchronous transfers.  Worth it when the same host buffers are used for many batches (registering 150 MB costs
-        about as much as copying it once).  Returns False on back-ends without the capability (tests/emu)."""
+        about as much as copying it once).  Returns False on back-ends without the capability (tests/emu).
+        LIFETIME: with pinned buffers collect() / align() return views of one of TWO pinned output pairs used in turn: a result
+        stays valid while the next batch is collected and is overwritten by the collect() after that; BatchResult.copy() detaches it."""
         L = getattr(self.parts[0], "_L", None)
         if L is None or not hasattr(L, "ipx_pin_host"):
             return False
         self.unpin()
         n = jobs.n_jobs
         caps = sum(max(1024, (b1 - b0) * cigar_ops_per_job) for b0, b1 in zip(shard_bounds(n, len(self.parts))[:-1], shard_bounds(n, len(self.parts))[1:]))
-        out = (np.empty(n, RESULT_DTYPE), np.empty(caps, np.uint32))
-        for a in (jobs.reads, jobs.read_off, jobs.refs, jobs.ref_off, jobs.ref_id, jobs.gap_open, jobs.gap_ext, jobs.mask_len) + out:
+        # TWO output pairs used in alternation: the BatchResult of one collect() stays valid while the next batch is collected
+        # (it is overwritten by the collect() after that; callers that keep results longer copy them: BatchResult.copy()).
+        out = [(np.empty(n, RESULT_DTYPE), np.empty(caps, np.uint32)) for _ in (0, 1)]
+        for a in (jobs.reads, jobs.read_off, jobs.refs, jobs.ref_off, jobs.ref_id, jobs.gap_open, jobs.gap_ext, jobs.mask_len) + out[0] + out[1]:
             if a is not None and a.nbytes and L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
                 self._pinned.append(a)
         self._out = out
@@ -441,7 +508,7 @@ class MultiStreamAligner:
 
     def upload(self, jobs):
         k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
-        b = shard_bounds(jobs.n_jobs, k)
+        b = shard_bounds(jobs.n_jobs, k, jobs if self.balance_by_cells else None)
         self._active = self.parts[:k]
         self._slices = [jobs.shard(b[i], b[i + 1]) for i in range(k)]
         for p, j in zip(self._active, self._slices):
@@ -498,7 +565,7 @@ class MultiStreamAligner:
 
     def collect(self):
         jobs = self._submitted
-        if self._out is not None and len(self._out[0]) == jobs.n_jobs and hasattr(self._active[0], "download_async_into"):
+        if self._out is not None and len(self._out[0][0]) == jobs.n_jobs and hasattr(self._active[0], "download_async_into"):
             got = self._align_tail_async()
             if got is not None:
                 return got
@@ -511,7 +578,8 @@ class MultiStreamAligner:
     def _align_tail_async(self, cigar_ops_per_job=16):
         """sync slice k, start its download into the pinned output buffers, go on to slice k+1: a slice's records travel while
         the later slices still compute.  None when something did not fit (the caller falls back to the blocking path)."""
-        rec, pool = self._out
+        rec, pool = self._out[self._out_turn]
+        self._out_turn ^= 1
         lo = pb = 0
         try:
             for p in self._active:
@@ -566,9 +634,18 @@ def device_count():
     return int(_lib.lib().ipx_device_count())
 
 
-def shard_bounds(n_jobs, n_shards):
-    """Contiguous, near-equal job ranges: shard k owns [b[k], b[k+1])."""
-    return [n_jobs * k // n_shards for k in range(n_shards + 1)]
+def shard_bounds(n_jobs, n_shards, jobs=None):
+    """Contiguous job ranges, shard k owns [b[k], b[k+1]).  Without a table: near-equal job COUNTS.  With the job table: near-equal
+    WORK -- cumulative read length x window length, the cell count of the forward pass -- so that a table sorted by read length (the
+    length-bucketed table of SURVEY.md 8e) does not hand the last shard three times the first one's cells."""
+    if jobs is None or n_shards <= 1 or n_jobs == 0:
+        return [n_jobs * k // n_shards for k in range(n_shards + 1)]
+    cells = np.cumsum(np.diff(jobs.read_off).astype(np.float64) * np.diff(jobs.ref_off)[jobs.ref_id])
+    cuts = np.searchsorted(cells, cells[-1] * np.arange(1, n_shards) / n_shards, side="left") + 1
+    b = [0] + [int(min(max(c, 0), n_jobs)) for c in cuts] + [n_jobs]
+    for k in range(1, len(b)):                                     # monotone (degenerate tables: empty shards are fine)
+        b[k] = max(b[k], b[k - 1])
+    return b
 
 
 def align_sharded(jobs, aligners):
@@ -607,3 +684,15 @@ def merge_results(parts):
         base += len(p.cigar_pool)
     return BatchResult(np.concatenate(recs) if recs else np.zeros(0, RESULT_DTYPE),
                        np.concatenate(pools) if pools else np.zeros(0, np.uint32))
+
+
+def align_loci(tables, match_score=2, mismatch_penalty=2, device=0, aligner=None):
+    """MANY loci, one GPU batch: tables = one JobTable per locus (e.g. retarget_jobs / realign_pileup_jobs of each).  Returns one
+    BatchResult per locus.  aligner: a MultiStreamAligner / GpuAligner to reuse (its scoring is left as it is); else the shared
+    one of `device` with (match_score, mismatch_penalty)."""
+    tables = list(tables)
+    if aligner is None:
+        from .sswpy import _gpu
+        aligner = _gpu(device)
+        aligner.set_scoring(matrix=dna_score_matrix(match_score, mismatch_penalty), flag=1, score_size=2)
+    return aligner.align(JobTable.concat(tables)).split([t.n_jobs for t in tables])

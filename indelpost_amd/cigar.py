@@ -6,9 +6,9 @@ Mirrors (citations into /root/reference/indelpost/):
   to_minimal_repeat_unit                         utilities.pyx:150-166
 Same names, arguments and return shapes (lists of dicts with the reference's keys), so the callers of the
 reference (retarget, pileup.pyx:650-711; update_read_info, pileup.pyx:849-880) read the same values.  Their
-reference modules cimport pysam and cannot be imported in the build container: parity of these decoders is pinned
-by hand-derived known answers on the CIGAR known-answer vectors of SURVEY.md 8c (tests/test_decoders.py), not by an
-executable reference -- "parity unpinned" in the sense of DESIGN.md section 2.
+reference modules cimport pysam and cannot be imported in the build container; parity is PINNED all the same: the
+reference's own function bodies, read as text and executed, produced the vectors of tests/golden/decoder_cases.json
+(oracle/gen_decoder_golden.py), and tests/test_decoders.py replays them through these functions.
 """
 import re
 

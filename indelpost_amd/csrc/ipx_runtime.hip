@@ -698,6 +698,18 @@ int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int
     return w;
 }
 
+// FNV-1a (32 bit) of every job's BAM-encoded CIGAR ops, 2166136261 (the offset basis) for a job without one: what the test
+// suite's CPU checker reports per job (oracle/cpu_baseline.c), so whole batches can be compared op for op without a Python loop
+void ipx_cigar_hashes(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, uint32_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t h = 2166136261u;
+        const uint32_t *c = cigar_pool + rec[i].cigar_off;
+        for (int k = 0; k < rec[i].cigar_len; ++k) h = (h ^ c[k]) * 16777619u;
+        out[i] = h;
+    }
+}
+
 uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *reads, int64_t n, int32_t rl)
 {
     for (int64_t k = 0; k < n; ++k) {

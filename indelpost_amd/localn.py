@@ -11,9 +11,9 @@ Mirrors (all citations into /root/reference/indelpost/localn.pyx):
                                          (is_target_by_ssw :257-291, is_covering_target :293-430,
                                          is_compatible_repeats :433-459): score compare over whole result
                                          columns, string checks only for the reads that pass it.
-What stays with the caller is everything that needs the BAM read (the filters of :244-249: already
-target, reference-identical, mapq, is_worth_realn): they do not depend on the alignments and arrive
-here as a mask.
+find_targets_by_ssw takes the alignment-independent filters (:244-249) as a mask; find_by_smith_waterman_realn (further
+down) is the whole function with the reference's signature, filters included, and find_by_smith_waterman_realn_many
+runs it for many loci in one GPU batch.
 """
 import numpy as np
 
@@ -307,22 +307,40 @@ def find_by_smith_waterman_realn(target_indel, contig, pileup, match_score, mism
     reference contig under (gap_open, gap_ext) and to the mutant contig with gap_open = len(read), all in ONE GPU batch, and
     gets is_target / undetermined as is_target_by_ssw would have set them.  `contig` needs get_contig_seq(split=True) and
     get_reference_seq() (contig.pyx)."""
-    mut_ref_lt, mut_ref_mid, mut_ref_rt = contig.get_contig_seq(split=True)
-    ref_ref = contig.get_reference_seq()
-    pileup = [findall_mismatches(read) for read in pileup]
-    todo = []
-    for k, read in enumerate(pileup):
-        need = _needs_realn(read, target_indel, mapq_lim)
-        if need is False:
-            read["is_target"] = False
-        elif need:
-            todo.append(k)
-    if todo:
-        pairs = align_pileup([pileup[k]["read_seq"] for k in todo], mut_ref_lt + mut_ref_mid + mut_ref_rt, ref_ref, match_score,
-                             mismatch_penalty, gap_open_penalty, gap_extension_penalty, device)
-        for k, (ref_aln, mut_aln) in zip(todo, pairs):
-            _apply_ssw_verdict(pileup[k], target_indel, mut_ref_lt, mut_ref_mid, mut_ref_rt, ref_aln, mut_aln)
-    return pileup
+    return find_by_smith_waterman_realn_many([(target_indel, contig, pileup, match_score, mismatch_penalty, gap_open_penalty,
+                                               gap_extension_penalty, basequalthresh, mapq_lim)], device)[0]
+
+
+def find_by_smith_waterman_realn_many(requests, device=0):
+    """find_by_smith_waterman_realn for MANY loci in ONE GPU batch: requests = (target_indel, contig, pileup, match_score,
+    mismatch_penalty, gap_open_penalty, gap_extension_penalty, basequalthresh[, mapq_lim]) per locus (same match / mismatch
+    everywhere).  Returns the annotated pileups in request order."""
+    from .retarget import align_many
+    R, W, GO, GE, plans = [], [], [], [], []
+    for req in requests:
+        target_indel, contig, pileup, ms, mm, go, ge, _bq = req[:8]
+        mapq_lim = req[8] if len(req) > 8 else 1
+        lt, mid, rt = contig.get_contig_seq(split=True)
+        ref_ref, mut_ref = contig.get_reference_seq(), lt + mid + rt
+        pileup = [findall_mismatches(read) for read in pileup]
+        todo = []
+        for k, read in enumerate(pileup):
+            need = _needs_realn(read, target_indel, mapq_lim)
+            if need is False:
+                read["is_target"] = False
+            elif need:
+                todo.append(k)
+                seq = read["read_seq"]
+                R += [seq, seq]; W += [ref_ref, mut_ref]; GO += [go, len(seq)]; GE += [ge, ge]      # localn.pyx:253-255
+        plans.append((target_indel, pileup, todo, lt, mid, rt))
+    alns = align_many(R, W, GO, GE, requests[0][3], requests[0][4], device) if R else []
+    at, out = 0, []
+    for target_indel, pileup, todo, lt, mid, rt in plans:
+        for k in todo:
+            _apply_ssw_verdict(pileup[k], target_indel, lt, mid, rt, alns[at], alns[at + 1])
+            at += 2
+        out.append(pileup)
+    return out
 
 
 def parse_read_by_mut_aln(mut_aln, contig, read, indel_type):

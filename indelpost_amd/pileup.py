@@ -10,9 +10,10 @@ the best grid_search response (varaln.pyx:1200-1216); here those alignments are 
 the chosen penalty pair) and this module turns each into the read-dict surgery the reference performs: flanks and
 qualities left and right of the indel, window flanks trimmed to the aligned part, the read's BAM CIGAR rewritten from the
 realignment (soft clips, splice junctions re-inserted as N), positions and clip offsets updated.
-The gapped-alignment branch (leftalign_indel_read, pileup.pyx:822-846) needs the FASTA and is the caller's.
-Parity: pinned by vectors from the reference's own function bodies (oracle/gen_decoder_golden.py) for split_cigar,
-trim_ref_flank, update_cigar and update_read_positions; update_read_info_realn on top of them by hand-derived cases.
+update_read_info (further down) is the whole function with the reference's signature, gapped-alignment branch included.
+Parity: pinned by vectors from the reference's own function bodies -- split_cigar, trim_ref_flank, update_cigar and
+update_read_positions by oracle/gen_decoder_golden.py, update_read_info as a whole (through grid_search) by
+oracle/gen_driver_golden.py.
 """
 from .cigar import cigar_ptrn, findall_indels, make_insertion_first
 
@@ -180,8 +181,9 @@ def update_reads_batch(reads, ref_seqs, ref_starts, candidate_pos, candidate_ind
 # Mirrors pileup.pyx:51-434 (make_pileup, fetch_reads, dictize_read, get_ref_seq, leftalign_indel_read, is_end_dirty,
 # leftalign_cigar, parse_spliced_read, is_within_intron) and the helpers of utilities.pyx they call (:187-330, :429-503).
 # `bam` / `reference` are pysam duck types (indelpost_amd.bamio provides pysam-free ones); `target` is a Variant.
-# Parity: the pure helpers are pinned by vectors from the reference's function bodies (oracle/gen_decoder_golden.py);
-# make_pileup / dictize_read as a whole have no executable reference here (no pysam): hand-derived cases only.
+# Parity: pinned.  The pure helpers by vectors from the reference's function bodies (oracle/gen_variant_golden.py, "helpers");
+# make_pileup / fetch_reads / dictize_read / get_ref_seq as a whole by oracle/gen_driver_golden.py: the reference's own function
+# text run against duck-typed BAM segments, every read dict compared field by field (tests/test_drivers.py).
 # =====================================================================================================================
 import random
 
@@ -563,50 +565,89 @@ def _retarget_select(target, non_refs, alns, ref_seqs, ref_starts, make, window,
     return "done", (candidate, pick(cand_reads), ratio, pick(cand_refs), pick(cand_starts), [make(w) for w in pick(cand_refs)])
 
 
+class _RetargetSearch:
+    """One locus' retarget under a set of (gap_open, gap_ext) pairs, as a resumable search: jobs() lists the alignments the
+    current recursion level needs, feed() takes them and moves every pair to its answer or to the next (smaller) window.
+    retarget_many drives one search; grid_search_many drives the searches of many loci level by level, so that ALL their
+    alignments of a level are one GPU batch."""
+
+    def __init__(self, target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty, gap_pairs, unspl_loc_ref,
+                 require_exact_for_shiftable):
+        self.target, self.within, self.cutoff, self.exact = target, within, retargetcutoff, require_exact_for_shiftable
+        self.match_score, self.mismatch_penalty, self.gap_pairs, self.unspl = match_score, mismatch_penalty, list(gap_pairs), unspl_loc_ref
+        self.non_refs = _retarget_reads(target, pileup, mapq4retarget)
+        self.results, self.used = [None] * len(self.gap_pairs), [{} for _ in self.gap_pairs]
+        self.level = {g: window for g in range(len(self.gap_pairs))} if self.non_refs else {}
+        self._geom, self._order = {}, []
+
+    @property
+    def done(self):
+        return not self.level
+
+    def jobs(self):
+        """(read_seqs, window strings, gap_opens, gap_exts) of the current level, pair-major"""
+        from .retarget import get_local_reference
+        self._geom = {}
+        for w in set(self.level.values()):
+            refs, starts = [], []
+            for read in self.non_refs:
+                ref_seq, lt_len = get_local_reference(self.target, [read], w, self.unspl)
+                refs.append(ref_seq)
+                starts.append(self.target.pos + 1 - lt_len)
+            self._geom[w] = (refs, starts)
+        self._order = sorted(self.level)
+        R, W, GO, GE = [], [], [], []
+        for g in self._order:
+            for read, ref_seq in zip(self.non_refs, self._geom[self.level[g]][0]):
+                R.append(read["read_seq"]); W.append(ref_seq); GO.append(self.gap_pairs[g][0]); GE.append(self.gap_pairs[g][1])
+        return R, W, GO, GE
+
+    def feed(self, alns):
+        from .localn import make_aligner
+        n, nxt = len(self.non_refs), {}
+        make = lambda ref_seq: make_aligner(ref_seq, self.match_score, self.mismatch_penalty)
+        for q, g in enumerate(self._order):
+            w = self.level[g]
+            refs, starts = self._geom[w]
+            mine = alns[q * n:(q + 1) * n]
+            verdict, val = _retarget_select(self.target, self.non_refs, mine, refs, starts, make, w, self.within, self.cutoff, self.exact)
+            if verdict == "shrink":
+                nxt[g] = val
+            else:
+                self.results[g] = val
+                self.used[g] = {id(r): a for r, a in zip(self.non_refs, mine)}
+        self.level = nxt
+
+
+def run_retarget_searches(searches, device=0):
+    """drive any number of _RetargetSearch objects to completion: one GPU batch per recursion level for ALL of them.  (Searches
+    must share the scoring: match / mismatch of the first one is used for the batch.)"""
+    from .retarget import align_many
+    live = [s_ for s_ in searches if not s_.done]
+    while live:
+        R, W, GO, GE, cuts = [], [], [], [], []
+        for s_ in live:
+            r, w, go, ge = s_.jobs()
+            R += r; W += w; GO += go; GE += ge
+            cuts.append(len(r))
+        alns = align_many(R, W, GO, GE, live[0].match_score, live[0].mismatch_penalty, device)
+        at = 0
+        for s_, k in zip(live, cuts):
+            s_.feed(alns[at:at + k])
+            at += k
+        live = [s_ for s_ in live if not s_.done]
+
+
 def retarget_many(target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty, gap_pairs, unspl_loc_ref,
                   require_exact_for_shiftable, device=0):
     """retarget (pileup.pyx:577-808) for every (gap_open, gap_ext) of gap_pairs at once.  Returns (results, alignments):
     results[g] = what retarget(..., gap_pairs[g][0], gap_pairs[g][1], ...) returns (None, or the 6-tuple with SSW aligner
     objects last); alignments[g] = {id(read): Alignment} of the level that produced results[g] (update_read_info makes the same
     alignment again in the reference; the caller can reuse it)."""
-    from .localn import make_aligner
-    from .retarget import align_many, get_local_reference
-    non_refs = _retarget_reads(target, pileup, mapq4retarget)
-    results, used = [None] * len(gap_pairs), [{} for _ in gap_pairs]
-    if not non_refs:
-        return results, used
-    level = {g: window for g in range(len(gap_pairs))}               # pairs still searching -> their current window
-    while level:
-        geom = {}                                                    # window size -> (ref_seqs, ref_starts) of the reads
-        for w in set(level.values()):
-            refs, starts = [], []
-            for read in non_refs:
-                ref_seq, lt_len = get_local_reference(target, [read], w, unspl_loc_ref)
-                refs.append(ref_seq)
-                starts.append(target.pos + 1 - lt_len)
-            geom[w] = (refs, starts)
-        order = sorted(level)
-        R, W, GO, GE = [], [], [], []
-        for g in order:
-            refs = geom[level[g]][0]
-            for read, ref_seq in zip(non_refs, refs):
-                R.append(read["read_seq"]); W.append(ref_seq); GO.append(gap_pairs[g][0]); GE.append(gap_pairs[g][1])
-        alns = align_many(R, W, GO, GE, match_score, mismatch_penalty, device)
-        n = len(non_refs)
-        nxt = {}
-        for q, g in enumerate(order):
-            w = level[g]
-            refs, starts = geom[w]
-            mine = alns[q * n:(q + 1) * n]
-            make = lambda ref_seq: make_aligner(ref_seq, match_score, mismatch_penalty)
-            verdict, val = _retarget_select(target, non_refs, mine, refs, starts, make, w, within, retargetcutoff, require_exact_for_shiftable)
-            if verdict == "shrink":
-                nxt[g] = val
-            else:
-                results[g] = val
-                used[g] = {id(r): a for r, a in zip(non_refs, mine)}
-        level = nxt
-    return results, used
+    s_ = _RetargetSearch(target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty, gap_pairs, unspl_loc_ref,
+                         require_exact_for_shiftable)
+    run_retarget_searches([s_], device)
+    return s_.results, s_.used
 
 
 def retarget(target, pileup, window, mapq4retarget, within, retargetcutoff, match_score, mismatch_penalty, gap_open_penalty,

@@ -16,8 +16,9 @@ What is mirrored (citations into /root/reference/indelpost/):
   candidate extraction of retarget   pileup.pyx:650-711   -> indel_candidates (plain tuples instead of Variant objects)
   is_non_spurious_overhang, SSW part pileup.pyx:527-548   -> overhang_jobs / overhang_alignment_verdicts
   is_perfect_match                   varaln.pyx:1228-1234 -> perfect_match_batch
-Everything that needs a Variant (normalisation, equivalents, difflib matching of candidates, pileup.pyx:712-808) stays
-with the caller: it consumes the tuples returned here.
+The composed functions with the reference's signatures -- retarget (candidate matching with Variant objects, the window / 3
+recursion), update_read_info, filter_spurious_overhangs -- are in pileup.py, grid_search in varaln.py; they are built on the
+job tables and helpers here.
 """
 import numpy as np
 

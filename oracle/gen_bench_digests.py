@@ -3,7 +3,7 @@
 Runs the reference's own ssw.c (oracle/_ref/libssw_ref.so, compiled unmodified from /root/reference by
 oracle/Makefile) over the exact job tables bench.py times -- config 2a, 2b (first 100 000 reads, the SURVEY 8c
 checksum dataset, plus the full million), the config-4 and config-5 shapes -- and writes, per workload, the
-record digest of indelpost_amd.batch.record_digest together with plain sums, to tests/golden/bench_digests.json.
+record digest of indelpost_amd.batch.record_digest (xxHash64 over every public field and the per-job CIGAR hash) together with plain sums, to tests/golden/bench_digests.json.
 
     python oracle/gen_bench_digests.py          # about 1-2 minutes per million jobs on 8 cores
 """
@@ -26,6 +26,7 @@ def workloads():
     yield "2b", (3, 2), synth.config2_jobs(1_000_000, 3, 1)
     yield "4", (3, 2), synth.config4_jobs()
     yield "5", (3, 2), synth.config5_jobs()
+    yield "4x1250", (3, 2), synth.config4_jobs(n_windows=1250)      # chunk 0 of bench.py --sharded (1250 windows per GPU)
 
 
 def main():
@@ -35,10 +36,10 @@ def main():
     cores = len(os.sched_getaffinity(0))
     out = {"generator": "oracle/gen_bench_digests.py", "checker": "reference ssw.c (oracle/_ref/libssw_ref.so)", "workloads": {}}
     for name, scoring, jobs in workloads():
-        rec, wsum = O.cpu_batch_results(be, jobs, O.dna_matrix(*scoring), cores, with_wsum=True)
+        rec = O.cpu_batch_results(be, jobs, O.dna_matrix(*scoring), cores)
         assert (rec["is_null"] == 0).all()
         out["workloads"][name] = {
-            "scoring": list(scoring), "n_jobs": int(jobs.n_jobs), "digest": record_digest(rec, wsum),
+            "scoring": list(scoring), "n_jobs": int(jobs.n_jobs), "digest": record_digest(rec, rec["cigar_hash"]),
             "sum_score1": int(rec["score1"].astype(np.int64).sum()), "sum_score2": int(rec["score2"].astype(np.int64).sum()),
             "sum_cigar_len": int(rec["cigar_len"].astype(np.int64).sum()), "flag_nonzero": int((rec["flag"] != 0).sum()),
             "flag1": int((rec["flag"] == 1).sum())}

@@ -1,7 +1,8 @@
 """The N>1 path on CPU: two ranks over gloo (torch.distributed.run, 127.0.0.1).
 
-1. bench.py --sharded --backend emu: the real bench driver -- ONE job table cut with JobTable.shard, every rank aligning
-   its shard (emulated kernels in place of the GPU), rank 0 gathering inside the timed loop -- must print one JSON line.
+1. bench.py --sharded --backend emu: the real bench driver -- every rank generating and aligning the chunk of the config-4
+   table it owns (emulated kernels in place of the GPU), rank 0 gathering records and CIGARs with dist.gather of uint8 tensors
+   inside the timed loop -- must print one JSON line whose job total scales with the number of ranks.
 2. a bespoke worker that compares the gathered records with the unsharded run, job for job.
 No data-path collective exists in the product (jobs are independent)."""
 import json
@@ -25,8 +26,9 @@ def test_two_rank_gloo_bench_sharded(emu, hip_lib):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, p.stdout[-2000:]
     rec = json.loads(line[0])
-    assert rec["mode"] == "sharded" and rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
-    assert rec["config"]["jobs_total"] == 48 and rec["sum_score1"] > 0
+    assert rec["mode"] == "sharded" and rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["jobs_total"] == 2 * 48 and rec["config"]["jobs_per_gpu"] == 48 and rec["sum_score1"] > 0      # 48 jobs per rank (emu rehearsal)
+    assert "f16" in rec["dtype"]
 
 
 def test_two_rank_gloo_shard_and_gather(emu, tmp_path):

@@ -51,3 +51,43 @@ def test_overhang_filter_and_smith_waterman_realn_match_the_reference(cases, por
     n = sum(DR.replay(sc, cases["genomes"], parts=("overhangs", "realn", "parse", "perfect")) for sc in cases["scenarios"])
     assert n > 1000
     assert sum(1 for sc in cases["scenarios"] if sc["overhangs"]) >= 4
+
+
+def test_many_loci_share_one_batch_per_level(cases, port_as_gpu):
+    """grid_search_many / find_by_smith_waterman_realn_many: every scenario of the fixture as ONE request list -- the same
+    answers as locus by locus, from a handful of aligner calls (one per recursion level for the searches, one for the realignment)"""
+    from indelpost_amd import localn, pileup as P, retarget as RT, varaln
+    from indelpost_amd.variant import Variant
+    reqs, reqs2, exp = [], [], []
+    for sc in cases["scenarios"]:
+        genome = cases["genomes"][sc["genome"]]
+        fa = DR.Fasta({"chr1": genome})
+        chrom, pos, ref, alt = sc["target"]
+        target = Variant(chrom, pos, ref, alt, fa)
+        unspl = RT.UnsplicedLocalReference(chrom, pos, len(genome), sc["window"], fa)
+        pile, _ = P.make_pileup(target, DR.Bam("chr1", [DR.Segment(r) for r in sc["segments"]]), unspl, sc["exclude_duplicates"], sc["window"],
+                                sc["downsamplethresh"], sc["basequalthresh"])
+        reqs.append((target, DR.clone(pile), sc["window"], 1, sc["within"], sc["cutoff"], 3, 2, [tuple(p) for p in sc["grid"]], unspl, False))
+        pl = DR.clone(pile)
+        for r in pl:
+            r["is_target"] = r["read_name"] in sc["pre_target"]
+        reqs2.append((target, DR.Contig(*sc["contig"]), pl, 3, 2, 3, 1, sc["basequalthresh"]))
+        exp.append(sc)
+    g = RT._gpu(0)                                                    # (the patched factory: the PortAligner of this test)
+    c0 = g.n_calls
+    out = varaln.grid_search_many(reqs)
+    assert g.n_calls - c0 <= 4                                        # window, window / 3, / 9, / 27: one batch per level
+    for res, sc in zip(out, exp):
+        e = sc["grid_search"]
+        if e is None:
+            assert res is None
+        else:
+            assert DR.ser(res[0]) == e["candidate"] and (res[2], res[3]) == (e["gap_open"], e["gap_ext"])
+            assert [DR.ser_read(r) for r in res[1]] == e["reads"]
+    c0 = g.n_calls
+    out2 = localn.find_by_smith_waterman_realn_many(reqs2)
+    assert g.n_calls - c0 == 1
+    for res, sc in zip(out2, exp):
+        got = [{"read_name": r["read_name"], "is_target": r.get("is_target"), "undetermined": r.get("undetermined", False),
+                "mismatches#": DR.dig(r["mismatches"])} for r in res]
+        assert got == sc["realn"]
