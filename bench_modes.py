@@ -123,17 +123,17 @@ def run_sharded(ip, args, dist, rank, world, my_devices, aligner_cls):
         chunks = {k: c.shard(0, 48) for k, c in chunks.items()}
     aligners = [ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=args.streams, aligner_cls=aligner_cls)
                 for dev in my_devices]
-    for g in aligners:
+    pinned = []
+    for g, k in zip(aligners, mine):
         g.balance_by_cells = True                                # stream slices of near-equal work, not near-equal job count
+        pinned.append(bool(g.pin_host(chunks[k])) if hasattr(g, "pin_host") else False)   # staging buffers page-locked once, reused every step
 
     def step():
         parts = {}
         for g, k in zip(aligners, mine):
-            g.upload(chunks[k])
-            g.run()
+            g.submit(chunks[k])                                  # slice by slice: copy in, launch the pipeline; no waiting
         for g, k in zip(aligners, mine):
-            g.sync()
-            parts[k] = g.download()
+            parts[k] = g.collect()                               # slice by slice: wait, copy out (the later slices still compute)
         if dist is not None:                                     # host-side gather on rank 0 (no data-path collective on the GPUs)
             got = gather_bytes(dist, rank, world, [parts[rank].records.view(np.uint8).reshape(-1), np.ascontiguousarray(parts[rank].cigar_pool).view(np.uint8)])
             if rank != 0:
@@ -175,7 +175,8 @@ def run_sharded(ip, args, dist, rank, world, my_devices, aligner_cls):
                "config": {"workload": "config4: %d reads of 75/100/125/150/200/250 bp vs windows of 200-600 bp (one window per 996 reads), "
                                       "(3,2,3,1), %d windows per GPU; every rank generates and aligns its chunk (upload + run + download) and "
                                       "rank 0 gathers every record and CIGAR inside the timed region" % (jobs_total, wpg),
-                          "jobs_total": jobs_total, "jobs_per_gpu": jobs_total // max(1, n_parts), "streams_per_gpu": args.streams, "backend": args.backend}}
+                          "jobs_total": jobs_total, "jobs_per_gpu": jobs_total // max(1, n_parts), "streams_per_gpu": args.streams, "backend": args.backend,
+                          "pinned_host_buffers": all(pinned)}}
         out.update(chk)
         print(json.dumps(out))
     if dist is not None:

@@ -552,7 +552,7 @@ class MultiStreamAligner:
         collect() waits and fetches the results.  Two aligners used alternately (submit on one while collecting from the
         other) keep the GPU busy across batches: bench_modes.run_end_to_end."""
         k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
-        b = shard_bounds(jobs.n_jobs, k)
+        b = shard_bounds(jobs.n_jobs, k, jobs if self.balance_by_cells else None)
         self._active = self.parts[:k]
         self._submitted = jobs
 
@@ -640,11 +640,15 @@ def shard_bounds(n_jobs, n_shards, jobs=None):
     length-bucketed table of SURVEY.md 8e) does not hand the last shard three times the first one's cells."""
     if jobs is None or n_shards <= 1 or n_jobs == 0:
         return [n_jobs * k // n_shards for k in range(n_shards + 1)]
+    cache = jobs.__dict__.setdefault("_work_bounds", {})           # (a table's cuts are asked for again every step it is aligned)
+    if n_shards in cache:
+        return list(cache[n_shards])
     cells = np.cumsum(np.diff(jobs.read_off).astype(np.float64) * np.diff(jobs.ref_off)[jobs.ref_id])
     cuts = np.searchsorted(cells, cells[-1] * np.arange(1, n_shards) / n_shards, side="left") + 1
     b = [0] + [int(min(max(c, 0), n_jobs)) for c in cuts] + [n_jobs]
     for k in range(1, len(b)):                                     # monotone (degenerate tables: empty shards are fine)
         b[k] = max(b[k], b[k - 1])
+    cache[n_shards] = tuple(b)
     return b
 
 
@@ -674,16 +678,21 @@ def align_sharded(jobs, aligners):
 
 
 def merge_results(parts):
-    """Host-side gather: concatenate shard records, rebasing cigar offsets into one pool."""
-    recs, pools, base = [], [], 0
+    """Host-side gather: concatenate shard records, rebasing cigar offsets into one pool.  (One part: handed back as it is.)"""
+    parts = list(parts)
+    if len(parts) == 1:
+        return parts[0]
+    if not parts:
+        return BatchResult(np.zeros(0, RESULT_DTYPE), np.zeros(0, np.uint32))
+    rec = np.concatenate([p.records for p in parts])
+    lo = base = 0
     for p in parts:
-        r = p.records.copy()
-        r["cigar_off"] += np.uint32(base)
-        recs.append(r)
-        pools.append(p.cigar_pool)
+        n = len(p.records)
+        if base:
+            rec["cigar_off"][lo:lo + n] += np.uint32(base)
+        lo += n
         base += len(p.cigar_pool)
-    return BatchResult(np.concatenate(recs) if recs else np.zeros(0, RESULT_DTYPE),
-                       np.concatenate(pools) if pools else np.zeros(0, np.uint32))
+    return BatchResult(rec, np.concatenate([p.cigar_pool for p in parts]))
 
 
 def align_loci(tables, match_score=2, mismatch_penalty=2, device=0, aligner=None):

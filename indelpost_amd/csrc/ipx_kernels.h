@@ -612,6 +612,8 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
         }
         const pk16 bigthr = F16 ? pk_make((int)ipx_f16_from_uint((uint32_t)(127 + gE[0])), (int)ipx_f16_from_uint((uint32_t)(127 + gE[1])))
                                 : pk_make(127 + gE[0], 127 + gE[1]);  // F carry > 127+gapE: signed-byte compare territory
+        // (exact 8-bit stage) a cell can see a cut only with its largest carry below cutw and its main-loop H below cuth: see the lazy-F step
+        const pk16 cutw = pk_make(128 + 2 * gO[0] - gE[0], 128 + 2 * gO[1] - gE[1]), cuth = pk_make(128 + gO[0], 128 + gO[1]);
         pk16 D1, D2, D4, D8;                                    // decay of a carry across 1/2/4/8 whole segments
         {
             int d[2][4];
@@ -895,6 +897,7 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
                 vF = 0;
             } else {
                 pk16 fe = fast_static;
+                pk16 recheck = 0;                                   // (exact 8-bit stage) reads with a big carry in this column
                 if (BYTE) {
                     const pk16 big = pk_nzmask(pk_subus(vF, bigthr));
                     const pk16 anybig = group_or<W>(big);
@@ -904,7 +907,8 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
                     // small carries that the big one happened to dominate
                     if (LOW) { const pk16 drop = anybig & fast_static; vF &= ~drop; dropped |= drop; }
                     else if (HIGH) dropped |= anybig & fast_static;   // every carry is passed on; remember that the read had such a column
-                    else fe &= ~anybig;
+                    else if (F16) fe &= ~anybig;
+                    else recheck = anybig & fast_static;
                 }
                 pk16 x = xl_row_shr1(vF & fe);
                 if (W == 8 && l == 0) x = 0;
@@ -920,6 +924,31 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
                     y = xl_row_shr<2>(x); if (W == 8 && l < 2) y = 0; x = pk_max(x, pk_subus(y, D2));
                     y = xl_row_shr<4>(x); if (W == 8 && l < 4) y = 0; x = pk_max(x, pk_subus(y, D4));
                     if (W == 16) { y = xl_row_shr<8>(x); x = pk_max(x, pk_subus(y, D8)); }
+                    }
+                    if constexpr (BYTE && !LOW && !HIGH && !F16) {
+                        // Exact 8-bit stage, a read with a big carry in this column (r03).  The reference's loop can leave a carry
+                        // unapplied -- a CUT -- only at a step where that carry's value f lies in [128 + gapE, 128 + gapO) (f - gapE is
+                        // still a "negative" byte, H' - gapO with H' = max(H, f) no longer is: the signed compare of ssw.c:311 says
+                        // "not greater" where the unsigned one says "greater") and nobody else votes.  Such a carry is within
+                        // gapO - gapE of the largest carry a arriving at that cell, so the cell has a in [128 + gapE, 128 + 2 gapO - gapE)
+                        // and a main-loop H below 128 + gapO.  No such cell in the column: every exit of the loop is one the unsigned
+                        // compare would have taken too, and the loop equals the closed form whatever the carries' size (checked column
+                        // by column against the stepped loop on 1.6 x 10^7 columns before it went in: 2-3 % of columns have such a
+                        // cell where 7-26 % have a big carry).  Only the reads WITH such a cell step through the reference's loop.
+                        if (xl_any(recheck != 0)) {
+                            pk16 a = x, cc = 0;
+                            IPX_UNROLL
+                            for (int j = 0; j < SMAX; ++j) {
+                                if (j < S) {
+                                    // (a >= 128 + gapE) and (a < 128 + 2 gapO - gapE) and (H[j] < 128 + gapO): all three differences non-zero
+                                    cc |= pk_minu(pk_minu(pk_subus(a, bigthr), pk_subus(cutw, a)), pk_subus(cuth, H[j]));
+                                    a = pk_subus(a, ge);
+                                }
+                            }
+                            const pk16 cutcap = pk_nzmask(group_or<W>(cc)) & recheck;
+                            fe &= ~cutcap;                          // these reads keep their carries for the stepped loop below
+                            x &= ~cutcap;
+                        }
                     }
                     cmx = pk_max(cmx, x);                       // (both non-negative: halves order like integers)
                     pk16 a = x;
