@@ -163,6 +163,7 @@ IPX_DEV int next_pass_key(const IpxBatch &b, const IpxResult &r, int readLen, bo
     case IPX_MODE_NEED_BYTE_LOW:
     case IPX_MODE_NEED_BYTE_LOW_CMP: pass = IPX_PASS_BYTE_LOW2; break;
     case IPX_MODE_NEED_BYTE_EXACT:
+    case IPX_MODE_NEED_BYTE_EXACT_P:
     case IPX_MODE_NEED_BYTE_EXACT_W: pass = IPX_PASS_BYTE_EXACT; break;
     case IPX_MODE_NEED_WORD: pass = IPX_PASS_WORD_FWD; lanes = 8; break;                     // ssw.c:844-847
     case IPX_MODE_BYTE:
@@ -1211,6 +1212,14 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
                         if (has_word) r.mode = IPX_MODE_WORD;
                         else if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }            // -> 16-bit pass (ssw.c:844-847)
                         else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }                                       // ssw.c:848-851
+                    } else if (r.mode == IPX_MODE_NEED_BYTE_EXACT_P) {
+                        // the stepped pass after a failed proof: the record holds the plain recurrence's outputs -- equal ones keep the
+                        // read on the plain reverse pass
+                        const unsigned sc = F16 ? ipx_f16_to_uint(bh) : bh;
+                        const bool same = r.score1 == (uint16_t)sc && r.ref_end1 == eref && r.read_end1 == end_read && r.score2 == (uint16_t)s2 && r.ref_end2 == e2;
+                        r.mode = (same && rev_needed(b, sc)) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE;
+                        r.score1 = (uint16_t)sc; r.ref_end1 = eref; r.read_end1 = end_read; r.read_begin1 = -1;
+                        r.score2 = (uint16_t)s2; r.ref_end2 = e2;
                     } else if (after_plain) {
                         const unsigned sc = F16 ? ipx_f16_to_uint(bh) : bh;
                         const bool same = cmp_plain && r.score1 == (uint16_t)sc && r.ref_end1 == eref && r.read_end1 == end_read &&
@@ -1589,7 +1598,7 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
                         // result is the reference's; at the overflow threshold it says nothing; in between it is the candidate
                         // k_prove_plain certifies -- the second-best column needs no proof when it was processed before any
                         // value >= 128 existed (or is the initial 0)
-                        if (bv >= (unsigned)(255 - b.bias)) r.mode = IPX_MODE_NEED_BYTE_LOW;
+                        if (bv >= (unsigned)(255 - b.bias)) r.mode = b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT : IPX_MODE_NEED_BYTE_LOW;
                         else if (bv < 128u) r.mode = rev_needed(b, bv) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE;
                         else r.mode = (s2 == 0 || (e2 >= 0 && (uint32_t)e2 < cbig)) ? IPX_MODE_NEED_FWD_PROOF : IPX_MODE_NEED_FWD_PROOF2;
                     } else r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
@@ -1856,7 +1865,7 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
                 const int8_t *rd = b.reads + b.read_off[i];       // straight from HBM: one letter per band row, requested a row ahead
                 const int rid = b.ref_id[i];
                 const bool proven = prove_band(b, r, rd, b.refs_packed + b.refp_off[rid], Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
-                r.mode = proven ? IPX_MODE_WORD : IPX_MODE_NEED_BYTE_CHECK;
+                r.mode = proven ? IPX_MODE_WORD : (b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
                 b.res[i] = r;
                 key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
             }
@@ -2035,7 +2044,7 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
                         }
                         if (!decided) open = true;
                         else {
-                            if (!REV) r.mode = ok ? (rev_needed(b, r.score1) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE) : IPX_MODE_NEED_BYTE_LOW_CMP;
+                            if (!REV) r.mode = ok ? (rev_needed(b, r.score1) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE) : (b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT_P : IPX_MODE_NEED_BYTE_LOW_CMP);
                             else {
                                 r.mode = IPX_MODE_BYTE;                      // certified: final; otherwise the stepped reverse pass decides
                                 if (!ok) { r.ref_begin1 = -1; r.read_begin1 = -1; }

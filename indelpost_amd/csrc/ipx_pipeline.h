@@ -349,17 +349,19 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             if (d.any_low) {
                 ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, be.flat_grid(b.n_jobs * 4), 64, 64 + 256 * IPX_PROVE_CHUNK, b, prove_chunk);
-                ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
-                ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1);
+                if (!b.exact_direct) {
+                    ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
+                    ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1);
+                }
             }
-            if (wf) {                                            // word-first reads whose overflow could not be proven
+            if (wf && !b.exact_direct) {                         // word-first reads whose overflow could not be proven
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
                 ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
             }
         } else {
         if (d.any_low)
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_FIRST, routing);
-        if (wf) {                                                // word-first reads whose overflow could not be proven
+        if (wf && !b.exact_direct) {                             // word-first reads whose overflow could not be proven
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
         }

@@ -36,7 +36,8 @@ enum {
     IPX_MODE_NEED_FWD_PROOF2 = 11, // ... and so does the second-best column
     IPX_MODE_NEED_BYTE_LOW = 12,   // plain recurrence reached the overflow threshold: the lower-bound stage decides (nothing to compare with)
     IPX_MODE_NEED_BYTE_LOW_CMP = 13,  // proof failed: the lower-bound stage runs and is compared with the plain outputs in the record
-    IPX_MODE_NEED_REV_PROOF = 14,  // begin position from the plain reverse recurrence in the record; its cell still needs the proof
+    IPX_MODE_NEED_REV_PROOF = 14,
+    IPX_MODE_NEED_BYTE_EXACT_P = 15,  // as NEED_BYTE_EXACT with the plain recurrence's outputs in the record: equal exact outputs keep the plain reverse pass  // begin position from the plain reverse recurrence in the record; its cell still needs the proof
     IPX_MODE_PENDING = 255,  // not processed yet
 };
 
@@ -81,6 +82,8 @@ enum {
     IPX_ROUTE_NO_PLAIN_FIRST = 256,  // 8-bit passes in the r02 bracket order (lower bound, upper bound, stepped) instead of plain recurrence + proof
     IPX_ROUTE_NO_CLASS_MERGE = 512,  // every segLen class keeps its own wavefront launch (no rare class served by a longer class's kernel)
     IPX_ROUTE_NO_TIERS = 1024,       // one wavefront launch per class even where several classes of one occupancy could share a launch (k_dp_skew_tier)
+    IPX_ROUTE_NO_EXACT_DIRECT = 2048, // a read the proofs leave open takes the lower-bound stage before the stepped one (r03 first half) instead of
+                                      //   the stepped pass at once (which steps only where a cut can happen and costs little more than the lower bound)
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 
@@ -115,6 +118,7 @@ struct IpxBatch {
                                 //   matrix entry is a half whose low byte is 0 and len * max(mat) <= 2047; 0 = never; speed only
     uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
     uint8_t plain_first;        // the 8-bit passes of this batch take the plain-first flow (IPX_PASS_BYTE_FIRST): speed only
+    uint8_t exact_direct;       // what the proofs (k_prove_overflow, k_prove_plain) leave open goes to the stepped pass at once: speed only
     const uint8_t *cls_map;     // [IPX_NUM_PASSES][IPX_NUM_CLASSES] class a job of (pass, class) is LISTED under, or nullptr = its own.  The
                                 //   wavefront kernels serve any read whose padded row count fits theirs (rows shifted down, k_dp_skew), so a
                                 //   rare class rides in the next populated one's launch instead of getting a launch to itself: speed only

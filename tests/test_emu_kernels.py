@@ -156,7 +156,7 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
 
 @pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE),
                                    (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE), (R.ROUTE_NO_PLAIN_FIRST,),
-                                   (R.ROUTE_NO_CLASS_MERGE,), (R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_VL2)])
+                                   (R.ROUTE_NO_CLASS_MERGE,), (R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_VL2), (R.ROUTE_NO_EXACT_DIRECT,)])
 def test_emu_routing_knobs_off(emu, golden_c, knobs):
     """The speed-only routing decisions (the upper-bound stage, 16-bit pass first, register-selector profile, column
     maxima in LDS, fused traceback launch) must not change any result: golden vectors with each turned off."""
@@ -220,7 +220,14 @@ def test_emu_bracket_certifies_or_steps(emu, oracle_mod, port):
     assert _launched(a, K_BYTE_PLAIN) == [5] and _launched(a, K_BYTE_LOW) == [] and _launched(a, K_BYTE_HIGH) == [] and _launched(a, K_WORD_FIRST) == []
     assert a.launches.get(a.key(K_PROVE_PLAIN, 0)) == 1 and a.launches.get(a.key(K_PROVE_PLAIN, 1)) == 1
     n_first, n_low2, n_exact, n_rev, n_rev_plain = a.pass_jobs[1], a.pass_jobs[8], a.pass_jobs[4], a.pass_jobs[6], a.pass_jobs[9]
-    assert n_first == 28 and n_low2 < 14 and n_exact <= n_low2 and n_rev_plain >= 28 - n_low2 and n_rev + n_rev_plain >= 28 and n_rev < 14
+    # what the proof leaves open goes to the stepped pass at once (it steps only where a cut can happen); equal outputs keep the plain reverse pass
+    assert n_first == 28 and n_low2 == 0 and 0 < n_exact < 14 and n_rev_plain >= 28 - n_exact and n_rev + n_rev_plain >= 28 and n_rev < 14
+    # ... or, first half of r03, through the lower-bound stage first: same records
+    q = emu(0, 3, 2)
+    q.set_routing(R.ROUTE_NO_EXACT_DIRECT)
+    res_q = q.align(jobs)
+    assert q.status == 0 and all(res_q.as_dict(i) == res.as_dict(i) for i in range(jobs.n_jobs))
+    assert q.pass_jobs[8] == n_exact and q.pass_jobs[4] <= q.pass_jobs[8]
     # the r02 order (lower bound, upper bound, stepped): same records
     o = emu(0, 3, 2)
     o.set_routing(R.ROUTE_NO_PLAIN_FIRST)

@@ -10,3 +10,10 @@ print("2b", g.traceback_routing())
 jobs=synth.config5_jobs(20000)
 g.upload(jobs); g.run(); g.sync()
 print("5", g.traceback_routing())
+jobs=synth.config4_jobs(n_windows=250)
+g.upload(jobs); g.run(); g.sync()
+print("4 (249k jobs)", g.traceback_routing())
+g.set_profiling(1)
+for _ in range(5): g.run(); g.sync()
+kt=g.kernel_times()
+print({k:(round(v[0]/5,3),v[1]//5) for k,v in kt.items() if k.startswith("traceback") or k.startswith("prove") or "exact" in k or "check" in k or "low2" in k or k.startswith("plan")})
