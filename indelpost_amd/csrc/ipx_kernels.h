@@ -1747,7 +1747,9 @@ IPX_DEV bool prove_ungapped(const IpxBatch &b, const IpxResult &r, const int8_t 
     }
     return false;
 }
-// gapped, banded lower bound (see above)
+// gapped, banded lower bound (see above).  r03: a vertical gap step INTO the first row of a segment is safe as well -- it is the
+// first, unconditional step of the reference's lazy-F loop (ssw.c:303-308) -- but what it leaves there is a final H only: the
+// next column's diagonal sees it, the row's E and the F chain below it do not (see k_prove_plain, which shares these moves).
 IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd, const int8_t *rf, int Lr, int refLen, int go, int ge,
                         const uint64_t *coltab)
 {
@@ -1756,9 +1758,9 @@ IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd,
     const int S8 = (Lr + 15) >> 4;                         // segLen of the 8-bit pass (ssw.c:166)
     const int d0 = r.ref_end1 - r.read_end1;               // column - row of the end diagonal
     bool proven = false;
-    int H[BW], F[BW];                                      // previous row: cell k is column (row + d0 - HB + k)
+    int Hm[BW], Hf[BW], F[BW];                             // previous row (main-loop H, final H, F entering the row): cell k is column (row + d0 - HB + k)
     IPX_UNROLL
-    for (int k = 0; k < BW; ++k) { H[k] = 0; F[k] = 0; }
+    for (int k = 0; k < BW; ++k) { Hm[k] = 0; Hf[k] = 0; F[k] = 0; }
     uint64_t win = 0;                                      // 4 bits per band cell: window letter, 7 = outside the window
     IPX_UNROLL
     for (int k = 0; k < BW; ++k) {
@@ -1773,14 +1775,14 @@ IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd,
         a_next = rd[rr < r.read_end1 ? rr + 1 : rr];
         if ((unsigned)a > 4u) a = 4;
         const uint64_t row = coltab[a];
-        const bool fopen = seg != 0;                       // a vertical gap may enter this row
+        const bool cross = seg == 0;                       // first row of a segment: a vertical gap enters through lazy-F's first step only
         int e = 0, hleft = 0;
         IPX_UNROLL
         for (int k = 0; k < BW; ++k) {
             const unsigned cl = (unsigned)(win >> (4 * k)) & 7u;
             int f = 0;
-            if (fopen && k + 1 < BW) {
-                const int f1 = F[k + 1] - ge, f2 = H[k + 1] - go;
+            if (k + 1 < BW) {
+                const int f1 = F[k + 1] - ge, f2 = Hm[k + 1] - go;
                 f = f1 > f2 ? f1 : f2;
                 if (f < 0) f = 0;
             }
@@ -1789,12 +1791,15 @@ IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd,
                 e = e1 > e2 ? e1 : e2;
                 if (e < 0) e = 0;
             }
-            int h = H[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
-            if (h < e) h = e;
-            if (h < f) h = f;
-            if (cl > 4u) { h = 0; e = 0; f = 0; }            // outside the window
-            if (h >= cap) proven = true;
-            H[k] = h; F[k] = f; hleft = h;
+            int hm = Hf[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
+            if (hm < e) hm = e;
+            if (hm < 0) hm = 0;
+            int hf, fk;
+            if (!cross) { if (hm < f) hm = f; hf = hm; fk = f; }
+            else { hf = hm > f ? hm : f; fk = 0; }
+            if (cl > 4u) { hm = 0; hf = 0; e = 0; fk = 0; }   // outside the window
+            if (hf >= cap) proven = true;
+            Hm[k] = hm; Hf[k] = hf; F[k] = fk; hleft = hm;
         }
         const int cn = rr + 1 + d0 + HB;                   // column entering the band on the next row
         const uint64_t cl = (cn >= 0 && cn < refLen) ? (uint64_t)(uint8_t)rf[cn] : 7u;
@@ -2083,7 +2088,7 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
 // register/LDS-resident kernel k_tb_fast<BW> (list BW-1 = lists + (BW-1)*n_jobs, counter BW-1), wider
 // ones straight to the general kernel (list 7 = `esc`, counter 7).
 #define IPX_TBF_MAXBW 7
-IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc)
+IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc, int all_general)
 {
     const int64_t chunk = (int64_t)IPX_BDIM * IPX_PLAN_ROUNDS, stride = (int64_t)IPX_GDIM * chunk;
     const int64_t iters = (b.n_jobs + stride - 1) / stride;
@@ -2099,7 +2104,7 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                 if (cigar_needed(b, r)) {
                     const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
                     const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-                    cls[k] = bw <= IPX_TBF_MAXBW ? bw - 1 : IPX_TBF_MAXBW;
+                    cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : IPX_TBF_MAXBW;   // (all_general: a small batch, one wave per job)
                 }
             }
         }

@@ -403,7 +403,10 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, word_halves);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
-            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc);
+            // a SMALL batch has more SIMDs than jobs: one wave per job (k_tb_coop: a DP row spread over the lanes) then finishes a typical job in
+            // a fifth of the time one lane needs for it (r03, 1000 jobs: 0.76 -> 0.42 ms of traceback), and the lane-per-job launch is skipped
+            const int tb_all_general = !(routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) && b.n_jobs <= 2048;
+            be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 0, b, ws.tb_list, ws.tb_list_n, ws.tb_esc, tb_all_general);
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
             const int want = d.max_read_len > 0 ? d.max_read_len : 1;
             const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;
@@ -416,7 +419,9 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // (each width has its own register footprint and occupancy)
             const int64_t fuse_max = (routing & IPX_ROUTE_TB_NO_FUSE) ? 0 : 20000;
             const int per_want = (int)((b.n_jobs + 63) / 64) + 1, per_have = ws.tbf_waves / 7;
-            if (b.n_jobs <= fuse_max && per_have >= 1) {
+            if (tb_all_general) {
+                // (nothing for the lane-per-job kernels)
+            } else if (b.n_jobs <= fuse_max && per_have >= 1) {
                 const int per = per_want < per_have ? per_want : per_have;
                 be.launch(IPX_KEY(IPX_K_TRACEBACK, 9), k_tb_fast_all, 7 * per, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
                           (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per, 0);

@@ -84,6 +84,7 @@ enum {
     IPX_ROUTE_NO_TIERS = 1024,       // one wavefront launch per class even where several classes of one occupancy could share a launch (k_dp_skew_tier)
     IPX_ROUTE_NO_EXACT_DIRECT = 2048, // a read the proofs leave open takes the lower-bound stage before the stepped one (r03 first half) instead of
                                       //   the stepped pass at once (which steps only where a cut can happen and costs little more than the lower bound)
+    IPX_ROUTE_TB_NO_WAVE_PER_JOB = 4096,  // small batches too take the lane-per-job traceback kernels (default: up to 2048 jobs, one wave per job)
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 

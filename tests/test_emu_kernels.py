@@ -154,9 +154,10 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
         assert res.as_dict(i) == port.align(reads[i], w, mat, 3, 1, mask_len=masks[i]), i
 
 
-@pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE),
+@pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE, R.ROUTE_TB_NO_WAVE_PER_JOB), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE),
                                    (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE), (R.ROUTE_NO_PLAIN_FIRST,),
-                                   (R.ROUTE_NO_CLASS_MERGE,), (R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_VL2), (R.ROUTE_NO_EXACT_DIRECT,)])
+                                   (R.ROUTE_NO_CLASS_MERGE,), (R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_VL2), (R.ROUTE_NO_EXACT_DIRECT,),
+                                   (R.ROUTE_TB_NO_WAVE_PER_JOB,), (R.ROUTE_TB_NO_WAVE_PER_JOB, R.ROUTE_TB_NO_FUSE, R.ROUTE_NO_MC_LDS)])
 def test_emu_routing_knobs_off(emu, golden_c, knobs):
     """The speed-only routing decisions (the upper-bound stage, 16-bit pass first, register-selector profile, column
     maxima in LDS, fused traceback launch) must not change any result: golden vectors with each turned off."""
@@ -310,7 +311,7 @@ def test_emu_band_doubling_stays_in_the_lane_per_job_kernels(emu, oracle_mod, po
     mat = oracle_mod.dna_matrix(3, 2)
     exp = [port.align(r, w, mat, int(jobs.gap_open[i]), int(jobs.gap_ext[i])) for i, r in enumerate(reads)]
     assert sum(1 for e in exp if e["cigar"] and sum(1 for c in e["cigar"] if c & 15) >= 2) >= 6      # both indels recovered
-    for routing in (R.ROUTE_TB_NO_FUSE, 0):
+    for routing in (R.ROUTE_TB_NO_FUSE | R.ROUTE_TB_NO_WAVE_PER_JOB, R.ROUTE_TB_NO_WAVE_PER_JOB, 0):
         a = emu(0, 3, 2)
         a.set_routing(routing)
         res = a.align(jobs)
