@@ -2360,7 +2360,9 @@ IPX_KERNEL_WAVE void k_tb_fast_all(IpxBatch b, const uint32_t *lists, const uint
 struct IpxTbScratch {
     uint8_t *dir;
     uint32_t *cig;
+    int32_t *band;            // band rows of jobs too wide for LDS: 4 * arrcap ints per block
     int32_t arrcap, dircap, cigcap;
+    int32_t arrcap_lds;       // band rows up to this many entries live in LDS
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2380,22 +2382,20 @@ struct IpxTbScratch {
 // an earlier, narrower band iteration alias exactly as in the reference; never-written cells read 0 = the
 // reference's "Trace back error" path (it reads uninitialised heap there) -- sit in a per-block global
 // scratch; the trace back itself is sequential (lane 0).
-// Dynamic LDS: 64 B matrix | 128 ints hand-over | 4 * arrcap ints (h_b, e_b, h_c, new e_b)
+// Dynamic LDS: 64 B matrix | 128 ints hand-over | 4 * arrcap_lds ints (h_b, e_b, h_c, new e_b).  A job whose band rows need more
+// (2 * max(aligned window span, aligned read span) + 8 entries: long reads, long deletions) keeps them in its block's region of the
+// global scratch instead (r03: windows up to 32 000 bp, reads up to 4 096 bp).
 // ------------------------------------------------------------------------------------------------
 static inline int ipx_tbc_lds_bytes(int arrcap) { return 64 + 512 + 16 * arrcap; }
 
 IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t *list_n, uint8_t *dir_scratch,
-                               int64_t dircap, int arrcap, uint32_t *cig_scratch, int cigcap)
+                               int64_t dircap, int arrcap_g, uint32_t *cig_scratch, int cigcap, int32_t *band_scratch, int arrcap_lds)
 {
     const int lane = lane_id();
     unsigned char *lds = IPX_LDS_BASE;
     int8_t *matl = (int8_t *)lds;
     int32_t *lastH = (int32_t *)(lds + 64);
     int32_t *lastF = lastH + 64;
-    int32_t *hb = lastF + 64;
-    int32_t *eb = hb + arrcap;
-    int32_t *hc = eb + arrcap;
-    int32_t *en = hc + arrcap;
     uint8_t *dir = dir_scratch + (int64_t)IPX_BID * dircap;
     uint32_t *cig = cig_scratch + (int64_t)IPX_BID * cigcap;
     if (lane < 25) matl[lane] = b.mat[lane];
@@ -2420,7 +2420,15 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
         const int len = refLen > readLen ? refLen : readLen;
         int mx = 0, width = 0, width_d = 0, extent = 0;
         bool broken = false;
-        for (int q = lane; q < arrcap; q += 64) { hb[q] = 0; eb[q] = 0; hc[q] = 0; en[q] = 0; }
+        // band rows: LDS when 2 * len + 8 entries fit there, else this block's region of the global scratch
+        const int need = 2 * (len > 0 ? len : 1) + 8;
+        const bool in_lds = need <= arrcap_lds;
+        const int arrcap = in_lds ? arrcap_lds : arrcap_g;
+        int32_t *hb = in_lds ? lastF + 64 : band_scratch + (size_t)IPX_BID * 4u * (size_t)arrcap_g;
+        int32_t *eb = hb + arrcap;
+        int32_t *hc = eb + arrcap;
+        int32_t *en = hc + arrcap;
+        for (int q = lane; q < (need < arrcap ? need : arrcap); q += 64) { hb[q] = 0; eb[q] = 0; hc[q] = 0; en[q] = 0; }
         IPX_SYNC();
 
         do {

@@ -441,9 +441,9 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             }
 #undef IPX_TBF_LAUNCH
             // everything else: one wavefront per job
-            be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_tb_coop, ws.tb1_waves, 64, ipx_tbc_lds_bytes(ws.tb1.arrcap), b,
+            be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_tb_coop, ws.tb1_waves, 64, ipx_tbc_lds_bytes(ws.tb1.arrcap_lds), b,
                       (const uint32_t *)ws.tb_esc, (const uint32_t *)ws.tb_esc_n, ws.tb1.dir, (int64_t)ws.tb1.dircap,
-                      ws.tb1.arrcap, ws.tb1.cig, ws.tb1.cigcap);
+                      ws.tb1.arrcap, ws.tb1.cig, ws.tb1.cigcap, ws.tb1.band, ws.tb1.arrcap_lds);
         }
     }
 }
@@ -600,7 +600,8 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
 }
 
 // scratch sizing shared by both back-ends -------------------------------------------------------
-struct IpxTbSizing { int arrcap, dircap, cigcap; };
+#define IPX_TBC_ARRCAP_LDS 2048     // band rows of up to this many entries stay in LDS (33 KB per one-wave block)
+struct IpxTbSizing { int arrcap, dircap, cigcap, arrcap_lds; };
 static inline IpxTbSizing ipx_tb1_sizing(const IpxDims &d)
 {
     IpxTbSizing s;
@@ -608,10 +609,11 @@ static inline IpxTbSizing ipx_tb1_sizing(const IpxDims &d)
     s.arrcap = 2 * (len > 0 ? len : 1) + 8;                      // band_width <= len (ssw.c:669)
     s.dircap = (2 * (len > 0 ? len : 1) + 1) * (d.max_read_len > 0 ? d.max_read_len : 1);
     s.cigcap = d.max_read_len + d.max_ref_len + 8;
+    s.arrcap_lds = s.arrcap < IPX_TBC_ARRCAP_LDS ? s.arrcap : IPX_TBC_ARRCAP_LDS;
     return s;
 }
 // the one-wave-per-job kernel needs direction bytes and CIGAR runs for ONE job per block
 static inline size_t ipx_tbc_bytes_per_block(const IpxTbSizing &s)
 {
-    return (((size_t)s.dircap + 15) & ~(size_t)15) + 4ull * (size_t)s.cigcap + 16;
+    return (((size_t)s.dircap + 15) & ~(size_t)15) + 4ull * (size_t)s.cigcap + 16 + (s.arrcap > s.arrcap_lds ? 16ull * (size_t)s.arrcap : 0ull);
 }

@@ -385,13 +385,16 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb1.arrcap = s1.arrcap; c->ws.tb1.dircap = (int32_t)(((size_t)s1.dircap + 15) & ~(size_t)15); c->ws.tb1.cigcap = s1.cigcap;
     c->ws.tb1.dir = c->tb1.as<uint8_t>();
     c->ws.tb1.cig = (uint32_t *)(c->tb1.as<char>() + (size_t)c->ws.tb1.dircap * (size_t)w1);
+    c->ws.tb1.arrcap_lds = s1.arrcap_lds;
+    c->ws.tb1.band = s1.arrcap > s1.arrcap_lds ? (int32_t *)((char *)c->ws.tb1.cig + (((4ull * (size_t)s1.cigcap * (size_t)w1) + 15) & ~15ull)) : nullptr;
 
     // column-maxima scratch of the forward passes: one region per DP block
     {
         const size_t per_block = 16 * (size_t)(d.max_ref_len + 8) * 4;
         int64_t cap = (int64_t)c->num_cu * IPX_DP_WAVES_PER_CU;
-        const int64_t fit = (int64_t)(IPX_DP_SCRATCH_BUDGET / per_block), floor_ = (int64_t)c->num_cu * 24;   // never below the resident count
-        if (cap > fit) cap = fit > floor_ ? fit : floor_;
+        // never below the resident count for ordinary windows; very long windows (tens of kilobases) keep to twice the budget instead
+        const int64_t fit = (int64_t)(IPX_DP_SCRATCH_BUDGET / per_block), floor_ = (int64_t)c->num_cu * 24, hard = (int64_t)(2 * IPX_DP_SCRATCH_BUDGET / per_block);
+        if (cap > fit) cap = fit > floor_ ? fit : (floor_ < hard ? floor_ : (hard > 64 ? hard : 64));
         c->dp_grid_cap = cap;
         if (c->maxcol.ensure((size_t)cap * per_block)) return IPX_ERR_NO_DEVICE;
     }

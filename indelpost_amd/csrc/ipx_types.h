@@ -91,7 +91,7 @@ enum {
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels
 #define IPX_SLOW_BASE (IPX_MAX_SEG + 1)      // class of a job with gap_open <= gap_ext: segLen + IPX_SLOW_BASE
 #define IPX_NUM_CLASSES (2 * IPX_SLOW_BASE)
-#define IPX_MAX_REFLEN 4096  // column maxima are staged in LDS
+#define IPX_MAX_REFLEN 32000 // columns are counted in 16-bit halves of packed registers (up to 32 767); column maxima in LDS when they fit, else global
 #define IPX_REF_PAD 8        // window starts are 4-byte aligned, with >= 4 readable bytes after the end
 
 // The batch as the kernels see it (all pointers are device pointers).

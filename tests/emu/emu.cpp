@@ -266,7 +266,8 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     memset(ws.tbf_scratch, 0x5A, ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 7);
     ws.tb1_waves = 2;
     memset(&ws.tb1, 0, sizeof ws.tb1);
-    ws.tb1.arrcap = s1.arrcap; ws.tb1.dircap = s1.dircap; ws.tb1.cigcap = s1.cigcap;
+    ws.tb1.arrcap = s1.arrcap; ws.tb1.dircap = s1.dircap; ws.tb1.cigcap = s1.cigcap; ws.tb1.arrcap_lds = s1.arrcap_lds;
+    ws.tb1.band = (int32_t *)malloc(16ull * (size_t)s1.arrcap * ws.tb1_waves + 64);
     ws.tb1.dir = (uint8_t *)malloc((size_t)s1.dircap * ws.tb1_waves + 64);
     ws.tb1.cig = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)s1.cigcap * ws.tb1_waves + 64);
     memset(ws.tb1.dir, 0x5A, (size_t)s1.dircap * ws.tb1_waves);
@@ -287,7 +288,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     free(b.maxcol_scratch);
     free(ws.plan_tables); free(ws.exact_starters); free(offs); free(perms);
     free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n);
-    free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tbf_scratch);
+    free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tb1.band); free(ws.tbf_scratch);
     free(dp);
     return 0;
 }

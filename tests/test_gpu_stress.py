@@ -211,11 +211,38 @@ def test_gpu_long_reads_and_long_windows(gpu, oracle_mod, capfd):
         _check_all(gpu, oracle_mod, jobs, scoring, capfd)
 
 
+def test_gpu_windows_of_tens_of_kilobases(gpu, oracle_mod, capfd):
+    """windows up to 32 000 bp (r03; the limit was 4 096): short reads against 20 kb windows, among them reads that bridge a deletion of
+    more than a kilobase under gap extension 0 -- their traceback band grows past what LDS holds and lives in the global scratch"""
+    rng = np.random.default_rng(777)
+    refs = [rng.integers(0, 4, n).astype(np.int8) for n in (20000, 31999, 5000)]
+    reads, rid, go, ge = [], [], [], []
+    for i in range(240):
+        k = i % 3
+        w = refs[k]
+        L = int(rng.integers(60, 400))
+        st = int(rng.integers(0, len(w) - 3000))
+        if i % 6 == 0:                                            # two halves 1.1-2.5 kb apart: one alignment with a long deletion when gap_ext = 0
+            gap = int(rng.integers(1100, 2500))
+            r = np.concatenate([w[st:st + L // 2], w[st + L // 2 + gap:st + gap + L]]).copy()
+        else:
+            r = w[st:st + L].copy()
+        m = rng.random(len(r)) < 0.02
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        reads.append(r); rid.append(k)
+        g = [(3, 0), (5, 0), (3, 1), (4, 0)][i % 4]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+    res = _check_all(gpu, oracle_mod, jobs, (3, 2), capfd)
+    span = res.records["ref_end1"] - res.records["ref_begin1"]
+    assert (span > 1100).sum() >= 20                              # the long deletions were bridged
+
+
 def test_gpu_limits_are_refused_loudly(gpu):
     import indelpost_amd as ip
     too_long_read = JobTable.from_sequences([np.zeros(513, np.int8)], [np.zeros(100, np.int8)], [0], 3, 1, encoded=True)
     with pytest.raises(ip.IpxError):
         gpu.align(too_long_read)
-    too_long_ref = JobTable.from_sequences([np.zeros(50, np.int8)], [np.zeros(4097, np.int8)], [0], 3, 1, encoded=True)
+    too_long_ref = JobTable.from_sequences([np.zeros(50, np.int8)], [np.zeros(32001, np.int8)], [0], 3, 1, encoded=True)
     with pytest.raises(ip.IpxError):
         gpu.align(too_long_ref)
