@@ -154,7 +154,7 @@ IPX_DEV int next_pass_key(const IpxBatch &b, const IpxResult &r, int readLen, bo
     case IPX_MODE_PENDING:
         if (b.score_size == 1) { pass = IPX_PASS_WORD_FWD; lanes = 8; }                      // 16-bit profile only (ssw.c:853-855)
         else if (b.score_size == 2 && b.word_first_len > 0 && readLen >= b.word_first_len) { pass = IPX_PASS_WORD_FIRST; lanes = 8; }
-        else if (b.plain_first) pass = slow ? IPX_PASS_BYTE_EXACT : IPX_PASS_BYTE_FIRST;     // plain recurrence first, certified afterwards (gap_open <= gap_ext: stepped at once)
+        else if (b.plain_first) pass = (slow || readLen > b.plain_max_len) ? IPX_PASS_BYTE_EXACT : IPX_PASS_BYTE_FIRST;   // plain recurrence first, certified afterwards (gap_open <= gap_ext, or beyond the plain kernels' reach: stepped at once)
         else if (readLen < b.byte_safe_len && (!b.use_bracket || readLen < b.bracket_min_len)) pass = IPX_PASS_BYTE_EXACT;
         else pass = IPX_PASS_BYTE_FIRST;                                                     // ssw.c:842-843
         break;
@@ -183,7 +183,7 @@ IPX_DEV int next_pass_key(const IpxBatch &b, const IpxResult &r, int readLen, bo
     }
     if (L < 0) L = 0;
     int cls = (L + lanes - 1) / lanes;
-    if (cls > IPX_MAX_SEG) { atomic_or_u32(b.status, IPX_STATUS_READ_TOO_LONG); return -1; }
+    if (cls > IPX_MAX_SEG) cls = IPX_MAX_SEG;                 // 64 segments or more: the long-read kernel's class (k_dp_long; upload refuses reads beyond its reach)
     if (slow) cls += IPX_SLOW_BASE;
     if (b.cls_map) cls = b.cls_map[pass * IPX_NUM_CLASSES + cls];                            // (a rare class rides in a longer class's launch)
     return pass * 256 + cls;
@@ -544,7 +544,8 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
         } else {
             for (; own_cls <= cls_hi; ++own_cls) {
                 const int sg = own_cls >= IPX_SLOW_BASE ? own_cls - IPX_SLOW_BASE : own_cls;
-                const bool foreign = sg < 64 && (((own_cls >= IPX_SLOW_BASE ? skip_slow : skip_fast) >> sg) & 1ull);   // owned by an exact-segLen launch
+                const bool foreign = sg == IPX_MAX_SEG ||                                                             // 64 segments or more: k_dp_long's
+                                     (((own_cls >= IPX_SLOW_BASE ? skip_slow : skip_fast) >> sg) & 1ull);             // owned by an exact-segLen launch
                 const uint32_t n = foreign ? 0u : p.tile_off[own_cls + 1] - p.tile_off[own_cls];
                 if (want < own_base + n) break;
                 own_base += n;
@@ -1708,6 +1709,231 @@ IPX_KERNEL_WAVE_OCC(ipx_tier_waves(SHI)) void k_dp_skew_tier(IpxBatch b, IpxPlan
 }
 
 #if IPX_AUX_KERNELS
+// ------------------------------------------------------------------------------------------------
+// k_dp_long<W, REV>: sw_sse2_byte (W = 16, ssw.c:197-384) / sw_sse2_word (W = 8, ssw.c:410-586) for reads too long for the
+// register-resident kernels (more than IPX_MAX_SEG = 64 striped segments: over 512 bp in the 16-bit pass, over 1 024 bp in the
+// 8-bit pass; r03: up to IPX_LONG_MAX_READ = 4 096 bp).  Correctness first, speed not at all: a plain transcription of the
+// reference's loop structure.  One read per 16-lane DPP row (4 per wave), one SSE lane per GPU lane (the 16-bit pass uses 8 lanes
+// of its row), one unpacked 32-bit value per lane; the striped columns H, E, the column saved at the best score and the read
+// letters of a row's segments live in the block's region of a global scratch, [segment][lane] (coalesced); the lazy-F loop is the
+// reference's, step by step, every read of the wave at its own (round, segment); column maxima go to the block's column-maxima
+// scratch.  Serves the planner's class IPX_MAX_SEG ("64 segments or more", fast- and slow-gap alike) of any pass; the jobs of a
+// tile (the pass's tile size) are taken four at a time.  Finalisation and mode logic are k_dp_pass's for the exact stage.
+// ------------------------------------------------------------------------------------------------
+#define IPX_LONG_MAX_READ 4096
+static inline size_t ipx_long_state_bytes(int max_read_len)   // per block: H, E, Hmax (int32) + letters (int8), [segment][64 lanes]
+{
+    const size_t S = (size_t)((max_read_len + 7) / 8) + 1;
+    return S * 64 * 13 + 64;
+}
+IPX_DEV int group16_or_i(int x)
+{
+    uint32_t v = (uint32_t)x;
+    v |= xl_xor1(v); v |= xl_xor2(v); v |= xl_half_mirror(v); v |= xl_mirror(v);
+    return (int)v;
+}
+IPX_DEV int group16_max_i(int x)
+{
+    int y;
+    y = (int)xl_xor1((uint32_t)x); x = x > y ? x : y;
+    y = (int)xl_xor2((uint32_t)x); x = x > y ? x : y;
+    y = (int)xl_half_mirror((uint32_t)x); x = x > y ? x : y;
+    y = (int)xl_mirror((uint32_t)x); x = x > y ? x : y;
+    return x;
+}
+template <int W, bool REV>
+IPX_KERNEL_WAVE void k_dp_long(IpxBatch b, IpxPlan p, int na, int maxcols, int pass, unsigned char *state, int64_t state_stride)
+{
+    constexpr bool BYTE = W == 16;
+    const int lane = lane_id();
+    const int slot = lane >> 4, l = lane & 15;
+    const bool lane_on = l < W;                                        // the 16-bit pass uses 8 lanes of its row
+    int8_t *matl = (int8_t *)IPX_LDS_BASE;
+    if (lane < 25) matl[lane] = b.mat[lane];
+    IPX_SYNC();
+    unsigned char *st = state + (int64_t)IPX_BID * state_stride;
+    const int64_t cap = (state_stride - 64) / (64 * 13);               // segments the region holds
+    int32_t *Hs = (int32_t *)st, *Es = Hs + cap * 64, *HMs = Es + cap * 64;
+    int8_t *LET = (int8_t *)(HMs + cap * 64);
+    uint32_t *maxcol = b.maxcol_scratch + (size_t)IPX_BID * (size_t)(8 * maxcols);   // [column][4 slots]
+    const int bias = b.bias;
+
+    for (int half = 0; half < 2; ++half) {
+        const int cls = IPX_MAX_SEG + half * IPX_SLOW_BASE;
+        const uint32_t ntile = p.tile_off[cls + 1] - p.tile_off[cls];
+        const uint32_t nsub = (uint32_t)((na + 3) / 4);
+        for (uint32_t want = (uint32_t)IPX_BID; want < ntile * nsub; want += (uint32_t)IPX_GDIM) {
+            const uint32_t tile = want / nsub, sub = want % nsub;
+            const uint32_t first = p.cls_off[cls] + tile * (uint32_t)na + sub * 4u;
+            const uint32_t tile_end = p.cls_off[cls] + (tile + 1u) * (uint32_t)na;
+            uint32_t end = p.cls_off[cls + 1] < tile_end ? p.cls_off[cls + 1] : tile_end;
+            const int cnt = first >= end ? 0 : (end - first < 4u ? (int)(end - first) : 4);
+            if (cnt == 0) continue;
+            // ---- this row's read ----
+            int64_t job = -1;
+            int L = 0, ncol = 0, gO = 0, gE = 0, score1 = 0, rend1 = -1, S = 0;
+            const int8_t *rd = b.reads, *rf = b.refs_packed;
+            if (slot < cnt) {
+                job = (int64_t)p.perm[first + slot];
+                const int rid = b.ref_id[job];
+                rd = b.reads + b.read_off[job];
+                rf = b.refs_packed + b.refp_off[rid];
+                gO = b.gap_open[job]; gE = b.gap_ext[job];
+                if (!REV) { L = (int)(b.read_off[job + 1] - b.read_off[job]); ncol = b.ref_len[rid]; }
+                else {
+                    const IpxResult r = b.res[job];
+                    L = r.read_end1 + 1; if (L < 0) L = 0;
+                    ncol = r.ref_end1 + 1; if (ncol < 0) ncol = 0;
+                    score1 = r.score1; rend1 = r.read_end1;
+                }
+                S = (L + W - 1) / W;
+            }
+            if ((int64_t)S > cap) { if (l == 0) atomic_or_u32(b.status, IPX_STATUS_READ_TOO_LONG); S = 0; L = 0; ncol = 0; job = -1; }
+            const int Smax = (int)wave_umax((uint32_t)S);
+            const int T = (int)wave_umax((uint32_t)ncol);
+            for (int j = 0; j < Smax; ++j) {                           // state and letters of the row's segments
+                const int r = j + l * S;
+                int a = 5;                                             // 5 = padding row (scores 0 against everything, ssw.c:174-176 / 396-398)
+                if (lane_on && j < S && r < L) { a = rd[REV ? L - 1 - r : r]; if ((unsigned)a > 4u) a = 4; }
+                LET[j * 64 + lane] = (int8_t)a;
+                Hs[j * 64 + lane] = 0; Es[j * 64 + lane] = 0; HMs[j * 64 + lane] = 0;
+            }
+            for (int c = l; c < T; c += 16) maxcol[c * 4 + slot] = 0;   // maxColumn is calloc'ed (ssw.c:224 / 431)
+            IPX_SYNC();
+            int best = 0, endref = BYTE ? -1 : 0, Hlast = 0;
+            bool done = ncol == 0, ovf = false;
+            for (int t = 0; t < T; ++t) {
+                if (!xl_any(!done && t < ncol)) break;
+                const bool act = !done && t < ncol;
+                const int ri = REV ? ncol - 1 - t : t;                 // reference walks the window right to left in the reverse pass (ssw.c:253-257)
+                int c = act ? rf[ri] : 0;
+                if ((unsigned)c > 4u) c = 4;
+                // -- main loop (ssw.c:274-299 / 480-504)
+                int vH = (int)xl_row_shr1((uint32_t)Hlast);
+                if (l == 0) vH = 0;
+                int vF = 0, cmx = 0;
+                for (int j = 0; j < Smax; ++j) {
+                    if (act && lane_on && j < S) {
+                        const int a = LET[j * 64 + lane];
+                        const int pp = a < 5 ? matl[c * 5 + a] : 0;
+                        int h;
+                        if (BYTE) { h = vH + pp + bias; if (h > 255) h = 255; h = h > bias ? h - bias : 0; }
+                        else { h = vH + pp; if (h > 32767) h = 32767; if (h < -32768) h = -32768; }
+                        int e = Es[j * 64 + lane];
+                        if (h < e) h = e;
+                        if (h < vF) h = vF;
+                        if (cmx < h) cmx = h;
+                        vH = Hs[j * 64 + lane];
+                        Hs[j * 64 + lane] = h;
+                        if (j == S - 1) Hlast = h;
+                        const int tt = h > gO ? h - gO : 0;
+                        e = e > gE ? e - gE : 0;
+                        Es[j * 64 + lane] = e > tt ? e : tt;
+                        vF = vF > gE ? vF - gE : 0;
+                        if (vF < tt) vF = tt;
+                    }
+                }
+                // -- lazy-F (ssw.c:302-313 / 507-518), step by step; every row of the wave at its own (round, segment)
+                {
+                    bool fin = !act || S == 0;
+                    int kk = 0, jj = 0;
+                    while (xl_any(!fin)) {
+                        const int sh = (int)xl_row_shr1((uint32_t)vF);
+                        if (!fin && jj == 0) vF = l == 0 ? 0 : sh;     // _mm_slli_si128 at the start of a round
+                        int vote = 0;
+                        if (!fin && lane_on) {
+                            int h = Hs[jj * 64 + lane];
+                            if (h < vF) h = vF;
+                            if (cmx < h) cmx = h;
+                            Hs[jj * 64 + lane] = h;
+                            if (jj == S - 1) Hlast = h;
+                            const int hh = h > gO ? h - gO : 0;
+                            vF = vF > gE ? vF - gE : 0;
+                            vote = BYTE ? ((int8_t)(uint8_t)vF > (int8_t)(uint8_t)hh) : ((int16_t)(uint16_t)vF > (int16_t)(uint16_t)hh);
+                        }
+                        const int anyv = group16_or_i(vote);
+                        if (!fin) {
+                            if (!anyv) fin = true;                     // goto end
+                            else if (++jj == S) { jj = 0; if (++kk == W) fin = true; }
+                        }
+                    }
+                }
+                // -- column maximum, best score (ssw.c:316-337 / 521-539)
+                const int cmA = group16_max_i(lane_on ? cmx : 0);
+                if (act) {
+                    bool leave = false;
+                    if (cmA > best) {
+                        best = cmA;
+                        if (BYTE && best + bias >= 255) { ovf = true; leave = true; }        // break before recording (ssw.c:327)
+                        else {
+                            endref = ri;
+                            for (int j = 0; j < S; ++j) if (lane_on) HMs[j * 64 + lane] = Hs[j * 64 + lane];
+                        }
+                    }
+                    if (!leave) {
+                        if (l == 0) maxcol[ri * 4 + slot] = (uint32_t)cmA;
+                        if (REV && cmA == score1) leave = true;                              // maxColumn[i] == terminate
+                    }
+                    if (leave) done = true;
+                }
+            }
+            IPX_SYNC();
+            // ---- finalisation (k_dp_pass, exact stage) ----
+            uint32_t rmin = 0x7FFFFFFFu;
+            for (int j = S - 1; j >= 0; --j)
+                if (lane_on && HMs[j * 64 + lane] == best) rmin = (uint32_t)(j + l * S);
+            rmin = group_umin<16>(rmin);
+            int end_read = L - 1;
+            if ((int)rmin < end_read) end_read = (int)rmin;
+            int key = -1;
+            if (!REV) {
+                const int maskLen = job >= 0 ? mask_len_of(b, job, L) : 15;
+                int edgeL = endref - maskLen; if (edgeL < 0) edgeL = 0;
+                int edgeR = endref + maskLen; if (edgeR > ncol) edgeR = ncol;
+                if (BYTE) edgeR += 1;
+                uint64_t key2 = 0xFFFFFFFFull;                                             // (score2 = 0, ref_end2 = 0)
+                for (int col = l; col < ncol; col += 16)
+                    if (col < edgeL || col >= edgeR) {
+                        const uint64_t v = maxcol[col * 4 + slot];
+                        if (v > (key2 >> 32)) key2 = (v << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)col);
+                    }
+                {   // first strict maximum in scan order = largest value, then smallest column
+                    uint32_t hi = (uint32_t)(key2 >> 32), lo = (uint32_t)key2;
+                    const uint32_t him = group_umax<16>(hi);
+                    lo = group_umax<16>(hi == him ? lo : 0u);
+                    key2 = ((uint64_t)him << 32) | lo;
+                }
+                if (l == 0 && job >= 0) {
+                    IpxResult r = b.res[job];
+                    const bool has_word = r.mode == IPX_MODE_NEED_BYTE_CHECK || r.mode == IPX_MODE_NEED_BYTE_EXACT_W;
+                    const int s2 = maskLen >= 15 ? (int)(key2 >> 32) : 0;
+                    const int e2 = maskLen >= 15 ? (int)(0xFFFFFFFFu - (uint32_t)key2) : -1;
+                    if (BYTE && ovf) {
+                        if (has_word) r.mode = IPX_MODE_WORD;
+                        else if (b.score_size == 2) { r.mode = IPX_MODE_NEED_WORD; r.score1 = 255; }
+                        else { r.mode = IPX_MODE_FAIL; r.score1 = 255; }
+                    } else {
+                        r.mode = BYTE ? IPX_MODE_BYTE : ((pass & 0xFF) == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD);
+                        r.score1 = (uint16_t)best; r.ref_end1 = endref; r.read_end1 = end_read; r.read_begin1 = -1;
+                        r.score2 = (uint16_t)s2; r.ref_end2 = e2;
+                    }
+                    b.res[job] = r;
+                    key = next_pass_key(b, r, L, gO <= gE);
+                }
+            } else if (l == 0 && job >= 0) {
+                IpxResult r = b.res[job];
+                const unsigned best_rev = (BYTE && ovf) ? 255u : (unsigned)best;
+                r.ref_begin1 = endref;                                                     // ssw.c:885
+                r.read_begin1 = rend1 - end_read;                                          // ssw.c:886
+                if ((unsigned)score1 > best_rev) r.flag = 2;                               // ssw.c:888-891
+                b.res[job] = r;
+            }
+            if (!REV) plan_note(b, key);
+            IPX_SYNC();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_prove_overflow: the reference always runs the 8-bit pass first and only then the 16-bit pass
 // (ssw.c:842-847).  For reads that will almost surely overflow we run the 16-bit pass first

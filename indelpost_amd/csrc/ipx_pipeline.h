@@ -24,6 +24,9 @@ struct IpxWorkspace {
     uint32_t *tb_esc, *tb_esc_n;        // jobs the fast traceback hands to the general (one wave per job) kernel
     IpxTbScratch tb1;
     unsigned char *tbf_scratch;         // direction words of the fast traceback: ipx_tbf_scratch_bytes_per_block(rowcap) per block
+    unsigned char *long_state;          // k_dp_long: striped columns of reads beyond the register kernels, long_stride bytes per block (null: no such read)
+    int64_t long_stride;
+    int long_blocks;
     int tbf_waves, tb1_waves;
 };
 
@@ -32,7 +35,7 @@ struct IpxWorkspace {
 #endif
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
-#define IPX_MAX_READ_LEN (8 * IPX_MAX_SEG)
+#define IPX_MAX_READ_LEN IPX_LONG_MAX_READ   // longest read the library takes (beyond 8 * IPX_MAX_SEG = 512 bp: k_dp_long)
 
 // what the host knows about a batch: which classes can occur in which pass
 struct IpxDims {
@@ -50,6 +53,8 @@ struct IpxDims {
     uint8_t word_sets;                 // the fast-gap classes of the three 16-bit passes are launched from `set` (wavefront kernels throughout)
     uint8_t plain_first;               // the 8-bit passes take the plain-first flow (IpxBatch::plain_first)
     uint8_t high_sets;                 // (bracket flow) the upper-bound stage runs as a wavefront, launched from `set`
+    int word_from;                     // 16-bit fast-gap classes below this one are planned into `set`; from it on: class-by-class launches / k_dp_long
+    int plain_max_len;                 // plain-first flow: reads up to this length take the plain kernels
 };
 
 static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
@@ -108,6 +113,7 @@ static inline bool ipx_low2_ok(const IpxBatch &b, const IpxDims &d, int routing)
 #define IPX_KEY(kclass, sub) ((kclass) * 256 + (sub))
 #define IPX_NUM_KEYS (IPX_K_NUM * 256)
 #define IPX_SUB_GENERIC 140
+#define IPX_SUB_LONG 141      // k_dp_long (reads of 64 segments or more)
 
 template <class BE, int W, bool REV, int STAGE>
 static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int cls, int maxcols, int kclass, int pass, int routing)
@@ -184,23 +190,35 @@ static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int
 // prefix has the read's own class or the one below, so those get their exact-segLen launch and ONE
 // branch-guarded launch sweeps up every other class (it skips the tiles the exact launches own).
 // halves: bit 0 = the fast-gap classes, bit 1 = the slow-gap classes (gap_open <= gap_ext) of `has` are served here
+// fast_from: the fast-gap classes below it are served elsewhere (the wavefront launches of ipx_launch_skew_set)
 template <class BE, int W, bool REV, int STAGE>
-static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *has, int maxcols, int kclass, int pass, int routing, int halves = 3)
+static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const IpxWorkspace &ws, const uint8_t *has, int maxcols, int kclass, int pass, int routing,
+                          int halves = 3, int fast_from = 0, int na = 0)
 {
     uint64_t exact[2] = {0, 0};                                   // classes with their own launch: [0] fast, [1] slow gaps
-    bool rest = false;                                            // anything the exact launches do not cover?
+    bool rest = false, lng = false;                               // anything the exact launches do not cover?  any read of 64 segments or more?
     int need = 0;                                                 // ... and its largest segLen
     for (int half = 0; half < 2; ++half) {
         if (!((halves >> half) & 1)) { exact[half] = ~0ull; continue; }       // (not ours: the sweep below skips these tiles too)
         const uint8_t *hs = has + half * IPX_SLOW_BASE;
+        const int from = half == 0 ? fast_from : 0;
+        if (from > 0) exact[half] |= (from >= 64 ? ~0ull : ((1ull << from) - 1ull));   // (served elsewhere: the sweep skips them)
         int top = -1;
         for (int c = 0; c <= IPX_MAX_SEG; ++c) if (hs[c]) top = c;
-        for (int c = 0; c <= top && c <= IPX_MAX_EXACT; ++c) {
+        if (top >= IPX_MAX_SEG) lng = true;
+        for (int c = from; c <= top && c <= IPX_MAX_EXACT; ++c) {
             const bool own = REV ? (hs[c] || (c + 1 <= top && hs[c + 1])) : hs[c] != 0;
             if (own) { exact[half] |= 1ull << c; ipx_launch_dp_class<BE, W, REV, STAGE>(be, b, p, c + half * IPX_SLOW_BASE, maxcols, kclass, pass, routing); }
         }
-        for (int c = 0; c <= top; ++c)
-            if ((REV || hs[c]) && !(c < 64 && ((exact[half] >> c) & 1ull))) { rest = true; need = c > need ? c : need; }
+        for (int c = from; c <= top && c < IPX_MAX_SEG; ++c)
+            if ((REV || hs[c]) && !((exact[half] >> c) & 1ull)) { rest = true; need = c > need ? c : need; }
+    }
+    if (lng && ws.long_state) {
+        // reads of 64 segments or more (over 512 bp in the 16-bit passes, over 1 024 bp in the 8-bit passes): the long-read kernel
+        const int tile = na > 0 ? na : 128 / W;
+        int grid = be.dp_grid();
+        if (grid > ws.long_blocks) grid = ws.long_blocks;
+        be.launch(IPX_KEY(kclass, IPX_SUB_LONG), k_dp_long<W, REV>, grid, 64, 64, b, p, tile, maxcols, pass, ws.long_state, ws.long_stride);
     }
     if (!rest) return;
     // the sweep kernel keeps segLen registers for its largest class: size it for the largest class it
@@ -331,12 +349,12 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     if (low2) routing |= IPX_ROUTE_INTERNAL_VL2;
     const bool wf = b.score_size == 2 && d.any_wf;
     // the fast-gap classes of a 16-bit pass: from the planned set as wavefronts, or class by class (ipx_launch_dp); slow-gap classes always the latter
-    const int word_halves = d.word_sets ? 2 : 3;
+    const int word_from = d.word_sets ? d.word_from : 0;         // fast-gap 16-bit classes below this: wavefront launches from the planned sets
     const int prove_chunk = b.n_jobs >= IPX_PROVE_CHUNK_MIN_JOBS ? IPX_PROVE_CHUNK : 1;   // (small batches: shortest chain of rounds per wave)
     if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
         if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
-        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, word_halves);
+        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], ws, d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, 3, word_from, 16);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
         be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(cap), b, cap, prove_chunk);
@@ -351,19 +369,19 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, be.flat_grid(b.n_jobs * 4), 64, 64 + 256 * IPX_PROVE_CHUNK, b, prove_chunk);
                 if (!b.exact_direct) {
                     ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
-                    ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1);
+                    ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], ws, d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1, 0, low2 ? 16 : 8);
                 }
             }
             if (wf && !b.exact_direct) {                         // word-first reads whose overflow could not be proven
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
-                ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
+                ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], ws, d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing, 3, 0, low2 ? 16 : 8);
             }
         } else {
         if (d.any_low)
-            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_FIRST, routing);
+            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], ws, d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_FIRST, routing, 3, 0, ipx_first_na(b, d, routing));
         if (wf && !b.exact_direct) {                             // word-first reads whose overflow could not be proven
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
-            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing);
+            ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], ws, d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing, 3, 0, low2 ? 16 : 8);
         }
         if (b.use_bracket && d.any_low) {                        // upper-bound stage: certifies the lower-bound outputs or not
             uint8_t hs[IPX_NUM_CLASSES];                          // (fast-gap classes only: a slow-gap read is stepped, never bracketed)
@@ -373,18 +391,18 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // reads per wave (k_dp_skew BH, read lengths up to 256); otherwise column by column in the 8-bit layout
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_HIGH], IPX_PASS_BYTE_HIGH, d.high_sets ? 16 : 8);
             if (d.high_sets) ipx_launch_skew_set<BE, false, 1>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], d.set[IPX_PASS_BYTE_HIGH], maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
-            else ipx_launch_dp<BE, 16, false, IPX_STAGE_HIGH>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], hs, maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing);
+            else ipx_launch_dp<BE, 16, false, IPX_STAGE_HIGH>(be, b, ws.plan[IPX_PASS_BYTE_HIGH], ws, hs, maxcols, IPX_K_BYTE_HIGH, IPX_PASS_BYTE_HIGH, routing, 3, 0, 8);
         }
         }
         // reads the bounds left open: the reference's stepped lazy-F
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_EXACT], IPX_PASS_BYTE_EXACT, 8);
-        ipx_launch_dp<BE, 16, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_EXACT], has8_all, maxcols, IPX_K_BYTE_EXACT, IPX_PASS_BYTE_EXACT, routing);
+        ipx_launch_dp<BE, 16, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_EXACT], ws, has8_all, maxcols, IPX_K_BYTE_EXACT, IPX_PASS_BYTE_EXACT, routing, 3, 0, 8);
     }
     if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, 16, b.score_size == 1);
         if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing);
-        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], b.score_size == 1 ? has16_all : d.has16_low, maxcols,
-                                                     IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, word_halves);
+        ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], ws, b.score_size == 1 ? has16_all : d.has16_low, maxcols,
+                                                     IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, 3, word_from, 16);
     }
     if (b.flag != 0) {                                           // begin position (ssw.c:872-886)
         if (b.score_size != 1) {
@@ -395,12 +413,12 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, be.flat_grid(b.n_jobs * 4), 64, 64 + 256 * IPX_PROVE_CHUNK, b, prove_chunk);
             }
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
-            ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing);
+            ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], ws, has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing, 3, 0, 8);
         }
         if (b.score_size != 0) {
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, 16);
             if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing);
-            ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, word_halves);
+            ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], ws, has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, 3, word_from, 16);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             // a SMALL batch has more SIMDs than jobs: one wave per job (k_tb_coop: a DP row spread over the lanes) then finishes a typical job in
@@ -547,10 +565,10 @@ static inline void ipx_merge_classes(const uint32_t *n, int top, bool merge, uin
     }
 }
 // reverse pass: launches for c and c-1 of every kept forward class, every other prefix class listed under the next launch
-static inline void ipx_reverse_classes(const uint8_t *kept_a, const uint8_t *kept_b, int top, uint8_t *map, uint8_t *set)
+static inline void ipx_reverse_classes(const uint8_t *kept_a, const uint8_t *kept_b, int top, uint8_t *map, uint8_t *set, const uint8_t *extra)
 {
     for (int c = 1; c <= top; ++c)
-        if (kept_a[c] || (kept_b && kept_b[c])) { set[c] = 1; if (c > 1) set[c - 1] = 1; }
+        if (kept_a[c] || (kept_b && kept_b[c]) || (extra && extra[c])) { set[c] = 1; if (c > 1 && !(extra && extra[c] && !kept_a[c] && !(kept_b && kept_b[c]))) set[c - 1] = 1; }
     int target = -1;
     for (int c = top; c >= 0; --c) {
         if (set[c]) target = c;
@@ -563,37 +581,50 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
         for (int c = 0; c < IPX_NUM_CLASSES; ++c) d.cls_map[ps][c] = (uint8_t)c;
     memset(d.set, 0, sizeof d.set);
     d.word_sets = d.plain_first = d.high_sets = 0;
+    d.word_from = 0; d.plain_max_len = 0;
     const bool skew_ok = ipx_perm_profile_ok(b.mat, routing) && !(routing & (IPX_ROUTE_NO_F16 | IPX_ROUTE_NO_SKEW)) && b.f16_max_len > 0;
     if (!skew_ok) return;
     const bool merge = !(routing & IPX_ROUTE_NO_CLASS_MERGE);
+    // the wavefront kernels reach 32 segments (16 in the 8-bit dialect) and need every score of the class exact in a half; longer
+    // reads of the same batch keep the class-by-class launches (k_dp_pass, k_dp_long) and their own classes
+    const int fmax16 = b.f16_max_len / 8 < IPX_MAX_EXACT ? b.f16_max_len / 8 : IPX_MAX_EXACT;
+    const int fmax8 = b.f16_max_len / 16 < 16 ? b.f16_max_len / 16 : 16;
     uint32_t n16wf[IPX_MAX_SEG + 1], n16low[IPX_MAX_SEG + 1], n8low[IPX_MAX_SEG + 1];
     memset(n16wf, 0, sizeof n16wf); memset(n16low, 0, sizeof n16low); memset(n8low, 0, sizeof n8low);
-    int top16 = -1, top8 = -1;
+    int top16 = -1, top8 = -1, all16 = -1, all8 = -1;
     for (int len = 0; len <= IPX_MAX_READ_LEN; ++len) {
         const uint32_t n = d.lenhist[0][len];
         if (!n) continue;
         const int c8 = (len + 15) / 16, c16 = (len + 7) / 8;
         const bool wfirst = b.score_size == 2 && b.word_first_len > 0 && len >= b.word_first_len;
-        if (wfirst) n16wf[c16] += n; else { n16low[c16] += n; n8low[c8] += n; if (c8 > top8) top8 = c8; }
-        if (c16 > top16) top16 = c16;
+        if (c16 > all16) all16 = c16;
+        if (c16 <= fmax16) { (wfirst ? n16wf : n16low)[c16] += n; if (c16 > top16) top16 = c16; }
+        if (!wfirst && c8 > all8) all8 = c8;
+        if (!wfirst && c8 <= fmax8) { n8low[c8] += n; if (c8 > top8) top8 = c8; }
     }
-    // 16-bit passes: every fast-gap class must be within the wavefront kernels' reach (32 segments, scores exact in halves)
-    if (merge && b.score_size != 0 && top16 >= 1 && top16 <= IPX_MAX_EXACT && 8 * top16 <= b.f16_max_len) {
+    if (merge && b.score_size != 0 && top16 >= 1) {
         d.word_sets = 1;
+        d.word_from = fmax16 + 1;
         ipx_merge_classes(n16wf, top16, true, d.cls_map[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST]);
         ipx_merge_classes(n16low, top16, true, d.cls_map[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD]);
-        ipx_reverse_classes(d.set[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FWD], top16, d.cls_map[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV]);
+        // every prefix class up to fmax16 must land in a launch: a longer read's alignment may end anywhere
+        uint8_t reach[IPX_NUM_CLASSES];
+        memset(reach, 0, sizeof reach);
+        reach[all16 < fmax16 ? (all16 > 0 ? all16 : 1) : fmax16] = 1;
+        ipx_reverse_classes(d.set[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FWD], fmax16, d.cls_map[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], reach);
     }
-    // 8-bit passes as the plain recurrence: classes up to 16 segments of the 16-lane layout (= 32 of the 8-lane layout)
-    const bool plain_ok = b.score_size != 1 && top8 >= 1 && top8 <= 16 && 16 * top8 <= b.f16_max_len;
+    // 8-bit passes as the plain recurrence
+    const bool plain_ok = b.score_size != 1 && top8 >= 1;
     if (plain_ok && b.use_bracket && !(routing & IPX_ROUTE_NO_PLAIN_FIRST)) {
         d.plain_first = 1;
+        d.plain_max_len = 16 * fmax8;
         ipx_merge_classes(n8low, top8, merge, d.cls_map[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST]);
-        if (merge) ipx_reverse_classes(d.set[IPX_PASS_BYTE_FIRST], nullptr, top8, d.cls_map[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN]);
-        else for (int c = 1; c <= top8; ++c) d.set[IPX_PASS_BYTE_REV_PLAIN][c] = 1, d.cls_map[IPX_PASS_BYTE_REV_PLAIN][0] = 1;
-    } else if (plain_ok && b.use_bracket) {
-        // bracket flow: the upper-bound stage as a wavefront (r02), its rare classes merged as well.  (Only reads that reach the
-        // bracket length get there; the counts of all 8-bit starters are an upper bound, which is all the merge rule needs.)
+        if (merge) ipx_reverse_classes(d.set[IPX_PASS_BYTE_FIRST], nullptr, top8, d.cls_map[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], nullptr);
+        else { for (int c = 1; c <= top8; ++c) d.set[IPX_PASS_BYTE_REV_PLAIN][c] = 1; d.cls_map[IPX_PASS_BYTE_REV_PLAIN][0] = 1; }
+    } else if (plain_ok && b.use_bracket && top8 == all8) {
+        // bracket flow: the upper-bound stage as a wavefront (r02) when every 8-bit class of the batch is within its reach, its rare
+        // classes merged as well.  (Only reads that reach the bracket length get there; the counts of all 8-bit starters are an upper
+        // bound, which is all the merge rule needs.)
         d.high_sets = 1;
         ipx_merge_classes(n8low, top8, merge, d.cls_map[IPX_PASS_BYTE_HIGH], d.set[IPX_PASS_BYTE_HIGH]);
     }

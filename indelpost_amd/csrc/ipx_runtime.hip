@@ -73,7 +73,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_esc, tb1, maxcol, tbf;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
+    DevBuf perm, tb_list, tb_esc, tb1, maxcol, tbf, long_state;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -254,7 +254,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_esc, &c->tb1, &c->maxcol, &c->tbf})
+                      &c->tb_list, &c->tb_esc, &c->tb1, &c->maxcol, &c->tbf, &c->long_state})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -312,7 +312,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     }
     for (int64_t i = 0; i < n_jobs; ++i) {
         const int64_t len = read_off[i + 1] - read_off[i];
-        if (len < 0 || len > 8 * IPX_MAX_SEG) { set_err("read %lld has length %lld (limit %d)", (long long)i, (long long)len, 8 * IPX_MAX_SEG); return IPX_ERR_READ_TOO_LONG; }
+        if (len < 0 || len > IPX_LONG_MAX_READ) { set_err("read %lld has length %lld (limit %d)", (long long)i, (long long)len, IPX_LONG_MAX_READ); return IPX_ERR_READ_TOO_LONG; }
         ipx_dims_add_read(d, (int)len, gap_open[i] <= gap_ext[i]);
         if (ref_id[i] < 0 || ref_id[i] >= n_refs) { set_err("job %lld: ref_id %d out of range", (long long)i, ref_id[i]); return IPX_ERR_ARG; }
     }
@@ -399,6 +399,16 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         if (c->maxcol.ensure((size_t)cap * per_block)) return IPX_ERR_NO_DEVICE;
     }
 
+    // striped columns of reads beyond the register-resident kernels (k_dp_long): one region per block, only when such reads exist
+    c->ws.long_state = nullptr; c->ws.long_stride = 0; c->ws.long_blocks = 0;
+    if (d.max_read_len > 8 * (IPX_MAX_SEG - 1)) {          // class 64 ("64 segments or more") can occur: from 505 bp in the 16-bit passes
+        const size_t stride = ipx_long_state_bytes(d.max_read_len);
+        int blocks = 256;
+        if ((int64_t)blocks > c->dp_grid_cap) blocks = (int)c->dp_grid_cap;
+        if (c->long_state.ensure(stride * (size_t)blocks)) return IPX_ERR_NO_DEVICE;
+        c->ws.long_state = c->long_state.as<unsigned char>(); c->ws.long_stride = (int64_t)stride; c->ws.long_blocks = blocks;
+    }
+
     // small tables: count + cursor of every pass, class and tile offsets of every pass, planner statistics
     uint32_t *sm = c->small.as<uint32_t>();
     c->ws.plan_tables = sm; sm += IPX_PLAN_TABLE_WORDS;
@@ -461,6 +471,7 @@ int ipx_run(ipx_ctx *c)
         // first run of this batch under these parameters: the job lists of the passes every job starts in
         ipx_plan_classes(c->dims, b, c->routing);
         b.plain_first = c->dims.plain_first;
+        b.plain_max_len = c->dims.plain_max_len;
         b.cls_map = c->cls_map_dev;
         HIPCHK(hipMemcpyAsync(c->cls_map_dev, &c->dims.cls_map[0][0], sizeof c->dims.cls_map, hipMemcpyHostToDevice, c->stream));
         ipx_dims_finish(c->dims, b.word_first_len, c->score_size,

@@ -233,6 +233,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
     ipx_plan_classes(d, b, routing);
     b.plain_first = d.plain_first;
+    b.plain_max_len = d.plain_max_len;
     b.cls_map = &d.cls_map[0][0];
     ipx_dims_finish(d, b.word_first_len, score_size, b.plain_first ? 0 : ipx_exact_start_len(b.byte_safe_len, b.bracket_min_len, b.use_bracket));
 
@@ -272,6 +273,12 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.tb1.cig = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)s1.cigcap * ws.tb1_waves + 64);
     memset(ws.tb1.dir, 0x5A, (size_t)s1.dircap * ws.tb1_waves);
 
+    ws.long_state = nullptr; ws.long_stride = 0; ws.long_blocks = 0;
+    if (d.max_read_len > 8 * (IPX_MAX_SEG - 1)) {          // class 64 ("64 segments or more") can occur: from 505 bp in the 16-bit passes
+        ws.long_stride = (int64_t)ipx_long_state_bytes(d.max_read_len);
+        ws.long_blocks = be.dp_grid();
+        ws.long_state = (unsigned char *)malloc((size_t)ws.long_stride * ws.long_blocks);
+    }
     if (n_jobs > 0) {
         ipx_build_static_plans(be, b, ws, d, routing);
         ipx_run_pipeline(be, b, ws, d, routing);
@@ -288,7 +295,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     free(b.maxcol_scratch);
     free(ws.plan_tables); free(ws.exact_starters); free(offs); free(perms);
     free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n);
-    free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tb1.band); free(ws.tbf_scratch);
+    free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tb1.band); free(ws.tbf_scratch); free(ws.long_state);
     free(dp);
     return 0;
 }

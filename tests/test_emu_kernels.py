@@ -417,3 +417,29 @@ def test_emu_rare_classes_ride_along_and_tiers_share_a_launch(emu, oracle_mod, p
         else:
             assert tier(a0, K_BYTE_PLAIN) and not tier(a1, K_BYTE_PLAIN)
             assert (base.records["mode"] == 0).all()
+
+
+def test_emu_long_reads_take_the_long_read_kernel(emu, oracle_mod, port):
+    """reads beyond the register-resident kernels (more than 64 striped segments: over 512 bp in the 16-bit passes, over 1 024 bp in
+    the 8-bit ones) take k_dp_long, a transcription of the reference's loops with the striped columns in global memory -- forward,
+    reverse, 8-bit (a low-scoring long read never leaves it) and 16-bit, fast and slow gaps, next to ordinary reads in the same batch"""
+    rng = np.random.default_rng(4096)
+    w = rng.integers(0, 4, 700).astype(np.int8)
+    reads, go, ge = [], [], []
+    for i, ln in enumerate([530, 600, 150, 1100, 640, 75, 513]):
+        st = int(rng.integers(0, max(1, len(w) - ln))) if ln < len(w) else 0
+        r = np.resize(w[st:], ln).copy()
+        m = rng.random(ln) < (0.02 if i != 3 else 0.75)                   # the 1 100 bp read is mostly noise: it stays in the 8-bit pass
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        if i % 2 == 0:
+            r = np.concatenate([r[:ln // 3], r[ln // 3 + 5:]])
+        reads.append(r)
+        g = [(3, 1), (5, 0), (4, 1), (3, 1), (2, 2), (3, 1), (1, 0)][i]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), go, ge, encoded=True)
+    for ms, mm in ((3, 2), (1, 1)):
+        a = emu(0, ms, mm)
+        res = a.align(jobs)
+        assert a.status == 0
+        _compare(res, [(r, w, o_, e_) for r, o_, e_ in zip(reads, go, ge)], port, oracle_mod.dna_matrix(ms, mm))
+        assert any(k % 256 == 141 for k in a.launches)                    # IPX_SUB_LONG: the long-read kernel ran

@@ -211,6 +211,40 @@ def test_gpu_long_reads_and_long_windows(gpu, oracle_mod, capfd):
         _check_all(gpu, oracle_mod, jobs, scoring, capfd)
 
 
+def test_gpu_reads_of_kilobases_vs_windows_of_tens_of_kilobases(gpu, oracle_mod, capfd):
+    """r03: reads up to 4 096 bp (the limit was 512) take k_dp_long -- the reference's loops transcribed, striped columns in global
+    memory -- and the wave-per-job traceback with its band rows in global memory; here 513-4 000 bp reads against 3-20 kb windows,
+    indels of up to 40 bp, fast and slow gap penalties, two scorings, ordinary short reads in the same batch, every field and every
+    CIGAR against the compiled reference"""
+    rng = np.random.default_rng(2000)
+    refs = [rng.integers(0, 4, n).astype(np.int8) for n in (3000, 8000, 20000)]
+    reads, rid, go, ge = [], [], [], []
+    for i in range(48):
+        k = i % 3
+        w = refs[k]
+        L = int(rng.choice([513, 640, 1000, 1025, 2000, 3000, 4000])) if i % 4 else int(rng.integers(50, 512))
+        L = min(L, len(w) - 60)
+        st = int(rng.integers(0, len(w) - L - 50))
+        r = w[st:st + L].copy()
+        m = rng.random(L) < (0.0, 0.01, 0.05)[i % 3]
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        if i % 5 == 0:
+            cut = int(rng.integers(20, L - 20))
+            r = np.concatenate([r[:cut], r[cut + int(rng.integers(1, 40)):]])
+        if i % 5 == 1:
+            cut = int(rng.integers(20, L - 20))
+            r = np.concatenate([r[:cut], rng.integers(0, 4, int(rng.integers(1, 30))).astype(np.int8), r[cut:]])[:4096]
+        if i % 11 == 7:
+            r = rng.integers(0, 4, len(r)).astype(np.int8)                # noise: a long read that stays in the 8-bit pass
+        reads.append(r); rid.append(k)
+        g = [(3, 1), (5, 0), (1, 1), (4, 1), (2, 2), (3, 0)][i % 6]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+    for scoring in ((3, 2), (1, 1)):
+        res = _check_all(gpu, oracle_mod, jobs, scoring, capfd)
+    assert int(np.diff(jobs.read_off).max()) >= 4000 and (res.records["read_end1"] > 2000).any()
+
+
 def test_gpu_windows_of_tens_of_kilobases(gpu, oracle_mod, capfd):
     """windows up to 32 000 bp (r03; the limit was 4 096): short reads against 20 kb windows, among them reads that bridge a deletion of
     more than a kilobase under gap extension 0 -- their traceback band grows past what LDS holds and lives in the global scratch"""
@@ -240,7 +274,7 @@ def test_gpu_windows_of_tens_of_kilobases(gpu, oracle_mod, capfd):
 
 def test_gpu_limits_are_refused_loudly(gpu):
     import indelpost_amd as ip
-    too_long_read = JobTable.from_sequences([np.zeros(513, np.int8)], [np.zeros(100, np.int8)], [0], 3, 1, encoded=True)
+    too_long_read = JobTable.from_sequences([np.zeros(4097, np.int8)], [np.zeros(100, np.int8)], [0], 3, 1, encoded=True)
     with pytest.raises(ip.IpxError):
         gpu.align(too_long_read)
     too_long_ref = JobTable.from_sequences([np.zeros(50, np.int8)], [np.zeros(32001, np.int8)], [0], 3, 1, encoded=True)
