@@ -79,6 +79,33 @@ class _IntNumpy:
         return np.zeros(shape, dtype=np.int64)
 
 
+def float_split():
+    """utilities.split executed with numpy's own float64 np.zeros and its index arithmetic forced back to int where Cython's `cdef int`
+    declarations would do it (int(...) around the slice bounds): used only to CHECK that the integer stand-in above changes nothing"""
+    ns = {"re": re, "np": np, "cigar_ptrn": re.compile(r"[0-9]+[MIDNSHPX=]")}
+    src = strip_cython(function_text(os.path.join(REF, "utilities.pyx"), "split"))
+    exec(compile(src, "<utilities:split/float>", "exec"), ns)
+    f = ns["split"]
+
+    class IntIndex:                                                   # sequence wrapper: float slice bounds truncate like a C int
+        def __init__(self, d):
+            self.d = d
+
+        def __getitem__(self, k):
+            if isinstance(k, slice):
+                t = lambda v: None if v is None else int(v)
+                return IntIndex(self.d[slice(t(k.start), t(k.stop), t(k.step))])
+            return self.d[int(k)]
+
+        def __len__(self):
+            return len(self.d)
+
+    def run(data, *a, **kw):
+        lt, rt = f(IntIndex(data), *a, **kw)
+        return lt.d, rt.d
+    return run
+
+
 def load():
     ns = {"re": re, "np": _IntNumpy, "array": array, "cigar_ptrn": re.compile(r"[0-9]+[MIDNSHPX=]")}
     for n in ("to_flat_list", "to_minimal_repeat_unit", "repeat_counter", "count_lowqual_non_ref_bases", "get_mapped_subreads",
@@ -94,8 +121,14 @@ def vtuple(v):
     return [v.chrom, v.pos, v.ref, v.alt]
 
 
+FLOAT_SPLIT = None
+N_FLOAT_CHECKED = [0]
+
+
 def main():
+    global FLOAT_SPLIT
     F = load()
+    FLOAT_SPLIT = float_split()
     Variant = F["Variant"]
     rng = np.random.default_rng(424242)
     g = list(s(rng.integers(0, 4, 3000)))
@@ -194,6 +227,12 @@ def main():
                 continue
             for rev in (False, True):
                 lt, rt = F["split"](data, cs, tp, sp, is_for_ref=isref, reverse=rev)
+                try:                                              # the stand-in is value-preserving on every committed input
+                    flt, frt = FLOAT_SPLIT(data, cs, tp, sp, is_for_ref=isref, reverse=rev)
+                    assert (list(flt), list(frt)) == (list(lt), list(rt)), ("float path differs", cs, tp, sp, isref, rev)
+                    N_FLOAT_CHECKED[0] += 1
+                except (TypeError, IndexError):
+                    pass                                          # (float slice bounds that plain Python cannot index with: not comparable)
                 H["split"].append({"data": list(data) if tag == "qual" else data, "kind": tag, "cigar": cs, "target_pos": tp, "string_pos": sp,
                                    "is_for_ref": isref, "reverse": rev, "expect": [list(lt) if tag == "qual" else lt, list(rt) if tag == "qual" else rt]})
         pos = read_start + int(rng.integers(-5, r + 10))
@@ -224,7 +263,7 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "variant_cases.json"), "w") as f:
         json.dump(out, f)
         f.write("\n")
-    print(len(out["variants"]), len(out["equal"]), {k: len(v) for k, v in H.items()})
+    print(len(out["variants"]), len(out["equal"]), {k: len(v) for k, v in H.items()}, "split cases also run through the float path:", N_FLOAT_CHECKED[0])
 
 
 if __name__ == "__main__":

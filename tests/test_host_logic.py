@@ -261,3 +261,42 @@ def test_concat_and_split_round_trip(emu):
         if t.n_jobs:
             alone = a.align(t)
             assert all(p.as_dict(i) == alone.as_dict(i) for i in range(t.n_jobs))
+
+
+def test_pinned_output_bookkeeping_of_the_multi_stream_aligner(emu):
+    """collect() with page-locked output buffers (here: plain arrays handed in as if pin_host had made them): every slice is copied
+    into its range of ONE record array and its region of ONE cigar pool, cigar offsets rebased; two output pairs are used in turn, so
+    the result of one batch survives the collection of the next; a pool too small for a slice falls back to the blocking path"""
+    from indelpost_amd._lib import RESULT_DTYPE
+    rng = np.random.default_rng(31)
+    w = rng.integers(0, 4, 200).astype(np.int8)
+
+    def table(seed):
+        r2 = np.random.default_rng(seed)
+        reads = []
+        for i in range(10):
+            st = int(r2.integers(0, 120))
+            r = w[st:st + 60].copy()
+            r[int(r2.integers(0, 60))] ^= 1
+            if i % 3 == 0:
+                r = np.concatenate([r[:25], r[28:]])
+            reads.append(r)
+        return JobTable.from_sequences(reads, [w], [0] * 10, 3, 1, encoded=True)
+    a, b = table(1), table(2)
+    m = ip.MultiStreamAligner(0, 3, 2, streams=2, aligner_cls=emu)
+    m.min_jobs_per_stream = 4                                            # two slices of five jobs
+    plain_a, plain_b = m.align(a), m.align(b)                            # blocking path (no pinned outputs)
+    m._out = [(np.zeros(10, RESULT_DTYPE), np.zeros(4096, np.uint32)) for _ in (0, 1)]
+    got_a = m.align(a)
+    got_b = m.align(b)                                                   # the other output pair: got_a stays valid
+    for got, plain in ((got_a, plain_a), (got_b, plain_b)):
+        assert all(got.as_dict(i) == plain.as_dict(i) for i in range(10))
+    assert got_a.records is m._out[0][0] and got_b.records is m._out[1][0]
+    assert got_a.records["cigar_off"][5] >= 1024                         # second slice: rebased into its region of the pool
+    kept = got_a.copy()
+    m.align(b)                                                           # third collect: overwrites the first pair ...
+    assert all(kept.as_dict(i) == plain_a.as_dict(i) for i in range(10))   # ... the copy is unaffected
+    m._out = [(np.zeros(10, RESULT_DTYPE), np.zeros(1500, np.uint32)) for _ in (0, 1)]   # room for one slice's region only
+    small = m.align(a)                                                   # falls back to the blocking download
+    assert all(small.as_dict(i) == plain_a.as_dict(i) for i in range(10)) and small.records is not m._out[0][0]
+    m.close()
