@@ -2096,7 +2096,10 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
                 const int8_t *rd = b.reads + b.read_off[i];       // straight from HBM: one letter per band row, requested a row ahead
                 const int rid = b.ref_id[i];
                 const bool proven = prove_band(b, r, rd, b.refs_packed + b.refp_off[rid], Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
-                r.mode = proven ? IPX_MODE_WORD : (b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
+                // not proven: the 8-bit pass decides.  A read that could score well beyond the threshold (1.5 x) most likely does overflow:
+                // the lower-bound stage at 16 reads per wave sees that soonest; a borderline read most likely does not: the stepped pass at once
+                const bool likely = 2 * Lr * b.max_match >= 3 * (255 - b.bias);
+                r.mode = proven ? IPX_MODE_WORD : ((b.exact_direct && !likely) ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
                 b.res[i] = r;
                 key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
             }

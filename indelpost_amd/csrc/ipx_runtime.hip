@@ -461,6 +461,7 @@ int ipx_run(ipx_ctx *c)
     b.bracket_min_len = ipx_bracket_min_len(c->mat);
     b.f16_max_len = ipx_f16_max_len(c->mat);
     b.byte_safe_len = ipx_byte_safe_len(c->mat, c->bias);
+    { int mx = 0; for (int k = 0; k < 25; ++k) if (c->mat[k] > mx) mx = c->mat[k]; b.max_match = mx; }
     b.exact_direct = ipx_perm_profile_ok(c->mat, c->routing) && !(c->routing & IPX_ROUTE_NO_EXACT_DIRECT);   // (the stepped selector-profile kernels: cheap where no cut can happen)
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;

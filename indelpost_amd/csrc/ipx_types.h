@@ -119,6 +119,7 @@ struct IpxBatch {
                                 //   matrix entry is a half whose low byte is 0 and len * max(mat) <= 2047; 0 = never; speed only
     uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
     uint8_t plain_first;        // the 8-bit passes of this batch take the plain-first flow (IPX_PASS_BYTE_FIRST): speed only
+    int32_t max_match;          // largest matrix entry
     int32_t plain_max_len;      // plain-first flow: reads up to this length take the plain kernels, longer 8-bit starters the stepped pass at once
     uint8_t exact_direct;       // what the proofs (k_prove_overflow, k_prove_plain) leave open goes to the stepped pass at once: speed only
     const uint8_t *cls_map;     // [IPX_NUM_PASSES][IPX_NUM_CLASSES] class a job of (pass, class) is LISTED under, or nullptr = its own.  The

@@ -228,6 +228,7 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     b.bracket_min_len = ipx_bracket_min_len(mat);
     b.f16_max_len = ipx_f16_max_len(mat);
     b.byte_safe_len = ipx_byte_safe_len(mat, -bias);
+    { int mx = 0; for (int k = 0; k < 25; ++k) if (mat[k] > mx) mx = mat[k]; b.max_match = mx; }
     b.exact_direct = ipx_perm_profile_ok(mat, routing) && !(routing & IPX_ROUTE_NO_EXACT_DIRECT);   // (the stepped selector-profile kernels: cheap where no cut can happen)
     b.flag = (uint8_t)flag; b.score_size = (uint8_t)score_size; b.filters = (uint16_t)filters; b.filterd = filterd;
     b.res = out; b.cigar_pool = cigar_pool; b.cigar_cap = cigar_cap; b.cigar_cursor = &cursor; b.status = &status;
