@@ -1410,8 +1410,10 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
     pk16 ccol = pk_make(-l, -l);           // this lane's column, counted in processing order: t - l
     pk16 seen = 0;                         // (reverse) this read was seen to have reached its score
 
-    const int T = (int)wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1])));
-    const int TT = T > 0 ? T + (W - 1) : 0;                    // the last lane is W-1 columns behind the first
+    const int T = (int)xl_first(wave_umax((uint32_t)((tb[0] + ncol[0]) > (tb[1] + ncol[1]) ? (tb[0] + ncol[0]) : (tb[1] + ncol[1]))));   // (a scalar: the step loop's bounds are uniform)
+    // the last lane is W-1 columns behind the first; steps come in groups of four, the last group's surplus steps process columns past
+    // every window (letter 5: nothing improves, and the column maxima they store land in the 4 spare columns of the scratch)
+    const int TT = T > 0 ? (T + (W - 1) + 3) & ~3 : 0;
     uint32_t pairA = 0x14141414u, pairB = 0x14141414u;         // letters (x 4) of the first lane's next four columns: bytes (half 0, half 1) x 2 each
     uint32_t cur[2], nxt[2];
     IPX_UNROLL
@@ -1467,39 +1469,48 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
             pairA = pk_perm(x[1], x[0], REV ? 0x06020703u : 0x05010400u);
             pairB = pk_perm(x[1], x[0], REV ? 0x04000501u : 0x07030602u);
         }
-        const int tn = t0 + 4 < TT ? t0 + 4 : TT;
-        IPX_NOUNROLL
-        for (int t = t0; t < tn; ++t) {
+        // the four steps of the group, unrolled: which pair and which bytes of it a step takes are compile-time, and the
+        // hand-over registers (Hl_old / Hl_cur) rotate by renaming
+        IPX_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u;
             // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
-            const uint32_t ksel = (t & 1) ? 0x0c0c0302u : 0x0c0c0100u;
-            const uint32_t nl = pk_perm(0u, (t & 2) ? pairB : pairA, ksel);
+            const uint32_t nl = pk_perm(0u, (u & 2) ? pairB : pairA, (u & 1) ? 0x0c0c0302u : 0x0c0c0100u);
             const uint32_t up = xl_row_shr1(let);
             let = l == 0 ? nl : up;
             const uint32_t tab0 = *(const uint32_t *)(lds + (let & 0xFFu)), tab1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
             // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
             const pk16 vH = xl_row_shr1(Hl_old) & nz;
             pk16 vF = xl_row_shr1(vFend) & nz;
-            const pk16 pmu = xl_row_shr1(pm) & nz;
-            pk16 cmx = 0;
+            // The column maximum starts from what the lanes above found in this column, so that after the stripe it is the
+            // maximum over the lanes up to this one.  The lane's best below therefore also covers the rows ABOVE its own in the
+            // columns it has processed: harmless -- the lane that owns such a row records the same value at the same column, so
+            // neither the best, nor its first column, nor (smallest row wins) the row found in the snapshots changes.
+            pk16 cmx = xl_row_shr1(pm) & nz;
             dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
             vFend = vF;
             Hl_old = Hl_cur;
             Hl_cur = H[SA - 1];
-            pm = pk_max(cmx, pmu);                               // (non-negative halves order like integers)
+            pm = cmx;
             if (!REV && l == W - 1 && t >= W - 1) {              // column t-7 is complete
                 if (mc_lds) maxcol[(t - (W - 1)) * G + g] = pm; else store_global_u32(maxcol + ((t - (W - 1)) * G + g), pm);
             }
-            // -- this lane's best (ssw.c:521-539, per lane)
+            // -- this lane's best (ssw.c:521-539, per lane; non-negative halves order like integers)
             const pk16 nb = pk_max(lbest, cmx);
             const pk16 dif = nb ^ lbest;                         // a half that is not 0: strictly better
             lbest = nb;
-            if (xl_any(dif != 0)) {
-                pk16 m = pk_nzmask(dif);
+            if (!REV) {
+                // (forward: some lane of the wave improves in nearly every step -- no test, the selects cost less than the branch)
+                const pk16 m = pk_nzmask_pos(dif);
+                lcol = pk_select(m, ccol, lcol);
+                IPX_UNROLL
+                for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);
+            } else if (xl_any(dif != 0)) {
                 // Reverse pass: the score to reach is the maximum of this matrix (it is the forward optimum, and every local
                 // alignment inside the prefix rectangle is one of the forward matrix), so the one improvement whose column and
                 // H values are ever looked at is the one that reaches it: no bookkeeping for the others.
-                if (REV) m &= ~pk_nzmask(nb ^ term);
-                if (!REV || xl_any(m != 0)) {
+                const pk16 m = pk_nzmask_pos(dif) & ~pk_nzmask(nb ^ term);
+                if (xl_any(m != 0)) {
                     lcol = pk_select(m, ccol, lcol);
                     IPX_UNROLL
                     for (int j = 0; j < SMAX; ++j) HM[j] = pk_select(m, H[j], HM[j]);

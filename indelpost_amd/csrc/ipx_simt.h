@@ -229,7 +229,12 @@ IPX_DEV pk16 pkh_max3(pk16 a, pk16 b, pk16 c) { return IPX_PK(__builtin_elementw
 IPX_DEV pk16 pk_nzmask(pk16 x) { return pk_sub(0u, pk_minu(x, 0x00010001u)); }
 #if defined(IPX_CPU_EMU)
 IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { return (a & mask) | (b & ~mask); }
+IPX_DEV pk16 pk_nzmask_pos(pk16 x) { return pk_nzmask(x); }
 #else
+// the same for halves below 0x8000: 0 - x is negative exactly when x is not 0, its sign spread over the half is the mask -- two
+// packed instructions with inline constants (the compiler turns pk_nzmask into two compares, two selects and a v_perm); op_sel_hi 0
+// on the shift count: an integer inline constant fills the LOW half only, both halves must read that one
+IPX_DEV pk16 pk_nzmask_pos(pk16 x) { pk16 r; asm("v_pk_sub_i16 %0, 0, %1\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(r) : "v"(x)); return r; }
 // one v_bfi_b32 (left to itself the compiler sometimes splits it into v_and + v_and_or)
 IPX_DEV pk16 pk_select(pk16 mask, pk16 a, pk16 b) { pk16 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b)); return r; }
 #endif
