@@ -120,7 +120,8 @@ uint64_t ballot(bool p)
 
 static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::function<void()> &body)
 {
-    std::vector<unsigned char> lds((size_t)lds_bytes + 64, 0xCD);
+    const size_t LDS_GUARD = 16384;                                  // canary behind the block's LDS: a kernel that writes past its launch's allocation is caught below
+    std::vector<unsigned char> lds((size_t)lds_bytes + LDS_GUARD, 0xCD);
     g_fibers.assign((size_t)bdim, Fiber());
     g_slot[0].assign((size_t)bdim, 0);
     g_slot[1].assign((size_t)bdim, 0);
@@ -153,6 +154,11 @@ static void run_block(int bid, int gdim, int bdim, int lds_bytes, const std::fun
         if (!any) break;
     }
     g_cur = -1;
+    for (size_t k = 0; k < LDS_GUARD; ++k)
+        if (lds[(size_t)lds_bytes + k] != 0xCD) {
+            fprintf(stderr, "emu: block %d wrote LDS byte %zu, the launch reserved %d\n", bid, (size_t)lds_bytes + k, lds_bytes);
+            abort();
+        }
     for (int t = 0; t < bdim; ++t) free(g_fibers[t].stack);
     g_fibers.clear();
 }
