@@ -1965,6 +1965,7 @@ IPX_KERNEL_WAVE void k_dp_long(IpxBatch b, IpxPlan p, int na, int maxcols, int p
 // 255-bias the 8-bit pass overflows.  Still-unproven reads take the 8-bit pass as usual.
 // ------------------------------------------------------------------------------------------------
 #define IPX_PROVE_BAND 15
+#define IPX_PROVE_BAND_NARROW 5                 // r03: a band of 5 diagonals first (most reads with an indel stay within 2 of the end diagonal), 15 for the rest
 #define IPX_PROVE_CHUNK 4                       // blocks of 64 consecutive jobs whose still-unproven reads share the band rounds
 // LDS: 64 B score columns | 64 * IPX_PROVE_CHUNK queue entries | read staging (lds_cap bytes)
 static inline int ipx_prove_lds_bytes(int lds_cap) { return 64 + 256 * IPX_PROVE_CHUNK + lds_cap; }
@@ -1987,10 +1988,11 @@ IPX_DEV bool prove_ungapped(const IpxBatch &b, const IpxResult &r, const int8_t 
 // gapped, banded lower bound (see above).  r03: a vertical gap step INTO the first row of a segment is safe as well -- it is the
 // first, unconditional step of the reference's lazy-F loop (ssw.c:303-308) -- but what it leaves there is a final H only: the
 // next column's diagonal sees it, the row's E and the F chain below it do not (see k_prove_plain, which shares these moves).
+template <int BW>
 IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd, const int8_t *rf, int Lr, int refLen, int go, int ge,
                         const uint64_t *coltab)
 {
-    constexpr int BW = IPX_PROVE_BAND, HB = BW / 2;
+    constexpr int HB = BW / 2;
     const int cap = 255 - b.bias;
     const int S8 = (Lr + 15) >> 4;                         // segLen of the 8-bit pass (ssw.c:166)
     const int d0 = r.ref_end1 - r.read_end1;               // column - row of the end diagonal
@@ -2096,25 +2098,42 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
             if (open) queue[qn + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
             qn += (uint32_t)__builtin_popcountll(om);
         }
-        for (uint32_t q0 = 0; q0 < qn; q0 += 64) {
-            IPX_SYNC();                                            // queue entries written; the staging area is free
-            const bool mine = q0 + (uint32_t)lane < qn;
-            const int64_t i = mine ? cbase + (int64_t)queue[q0 + lane] : 0;
-            int key = -1;
-            if (mine) {
-                IpxResult r = b.res[i];
-                const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
-                const int8_t *rd = b.reads + b.read_off[i];       // straight from HBM: one letter per band row, requested a row ahead
-                const int rid = b.ref_id[i];
-                const bool proven = prove_band(b, r, rd, b.refs_packed + b.refp_off[rid], Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
-                // not proven: the 8-bit pass decides.  A read that could score well beyond the threshold (1.5 x) most likely does overflow:
-                // the lower-bound stage at 16 reads per wave sees that soonest; a borderline read most likely does not: the stepped pass at once
-                const bool likely = 2 * Lr * b.max_match >= 3 * (255 - b.bias);
-                r.mode = proven ? IPX_MODE_WORD : ((b.exact_direct && !likely) ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
-                b.res[i] = r;
-                key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
+        // band rounds over the queue: the narrow band first; what it leaves open is queued again (in place: entries are written
+        // behind the ones being read) for the wide band, whose verdict stands
+        for (int round = 0; round < 2; ++round) {
+            uint32_t qnext = 0;
+            for (uint32_t q0 = 0; q0 < qn; q0 += 64) {
+                IPX_SYNC();                                        // queue entries written; the staging area is free
+                const bool mine = q0 + (uint32_t)lane < qn;
+                const int64_t i = mine ? cbase + (int64_t)queue[q0 + lane] : 0;
+                int key = -1;
+                bool open = false;
+                if (mine) {
+                    IpxResult r = b.res[i];
+                    const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+                    const int8_t *rd = b.reads + b.read_off[i];   // straight from HBM: one letter per band row, requested a row ahead
+                    const int rid = b.ref_id[i];
+                    const int8_t *rf = b.refs_packed + b.refp_off[rid];
+                    const bool proven = round == 0 ? prove_band<IPX_PROVE_BAND_NARROW>(b, r, rd, rf, Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab)
+                                                   : prove_band<IPX_PROVE_BAND>(b, r, rd, rf, Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
+                    if (!proven && round == 0) open = true;
+                    else {
+                        // not proven: the 8-bit pass decides.  A read that could score well beyond the threshold (1.5 x) most likely does overflow:
+                        // the lower-bound stage at 16 reads per wave sees that soonest; a borderline read most likely does not: the stepped pass at once
+                        const bool likely = 2 * Lr * b.max_match >= 3 * (255 - b.bias);
+                        r.mode = proven ? IPX_MODE_WORD : ((b.exact_direct && !likely) ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
+                        b.res[i] = r;
+                        key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
+                    }
+                }
+                plan_note(b, key);
+                if (round == 0) {
+                    const uint64_t om = xl_ballot(open);
+                    if (open) queue[qnext + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
+                    qnext += (uint32_t)__builtin_popcountll(om);
+                }
             }
-            plan_note(b, key);
+            qn = qnext;
         }
     }
 }
@@ -2177,10 +2196,10 @@ IPX_DEV bool prove_plain_ungapped(const IpxBatch &b, const IpxProveTarget &t, co
     return t.e2 > cs && u - go - (t.e2 - cs - 1) * ge >= t.s2;
 }
 
-template <bool REV>
+template <bool REV, int BW>
 IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const int8_t *rd, const int8_t *rf, int go, int ge, const uint64_t *coltab)
 {
-    constexpr int BW = IPX_PROVE_BAND, HB = BW / 2;
+    constexpr int HB = BW / 2;
     const int S8 = (t.Lp + 15) >> 4;                       // segLen of the 8-bit pass (ssw.c:221)
     const int rows = 16 * S8;
     const int d0 = t.c1 - t.r1;
@@ -2255,10 +2274,12 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
     for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
         const int64_t cbase = chunk * CB * 64;
         uint32_t qn = 0;                                           // queued jobs (the same in every lane)
-        for (int round = 0; round < 2; ++round) {
-            // round 0: every job of the chunk, ungapped test, the rest queued; round 1: the queue, band
+        for (int round = 0; round < 3; ++round) {
+            // round 0: every job of the chunk, ungapped test, the rest queued; round 1: the queue, narrow band, the rest queued again (in
+            // place: entries are written behind the ones being read); round 2: the queue, wide band
             const uint32_t total = round == 0 ? (uint32_t)(CB * 64) : qn;
-            if (round == 1) IPX_SYNC();                            // queue entries written
+            uint32_t qnext = 0;
+            if (round >= 1) IPX_SYNC();                            // queue entries written
             for (uint32_t q0 = 0; q0 < total; q0 += 64) {
                 int64_t i = -1;
                 if (round == 0) { const int64_t ii = cbase + q0 + lane; if (ii < b.n_jobs) i = ii; }
@@ -2285,7 +2306,8 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
                         bool ok = false, decided = true;
                         if (sane) {
                             if (round == 0) { ok = prove_plain_ungapped<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i]); decided = ok; }
-                            else ok = prove_plain_band<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab);
+                            else if (round == 1) { ok = prove_plain_band<REV, IPX_PROVE_BAND_NARROW>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab); decided = ok; }
+                            else ok = prove_plain_band<REV, IPX_PROVE_BAND>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab);
                         }
                         if (!decided) open = true;
                         else {
@@ -2300,12 +2322,13 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
                     }
                 }
                 plan_note(b, key);
-                if (round == 0) {
+                if (round < 2) {
                     const uint64_t om = xl_ballot(open);
-                    if (open) queue[qn + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
-                    qn += (uint32_t)__builtin_popcountll(om);
+                    if (open) queue[qnext + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
+                    qnext += (uint32_t)__builtin_popcountll(om);
                 }
             }
+            qn = qnext;
         }
         IPX_SYNC();                                                // the queue is free for the next chunk
     }
