@@ -1407,6 +1407,9 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
     pk16 lbest = 0, lcol = 0;              // per lane: best H of its rows, first column with it (counted in processing order)
     uint32_t let = 0x1414u;                // window letters of this lane's column, TIMES FOUR (= byte offsets into the score table; low byte:
                                            //   low half's read), 5 = no column
+    uint32_t lsel0 = l == 0 ? 0x0c0c0100u : 0x0c0c0504u, lsel1 = l == 0 ? 0x0c0c0302u : 0x0c0c0504u;   // (see the step loop)
+    IPX_KEEP_VGPR(lsel0);
+    IPX_KEEP_VGPR(lsel1);
     pk16 ccol = pk_make(-l, -l);           // this lane's column, counted in processing order: t - l
     pk16 seen = 0;                         // (reverse) this read was seen to have reached its score
 
@@ -1475,9 +1478,8 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u;
             // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
-            const uint32_t nl = pk_perm(0u, (u & 2) ? pairB : pairA, (u & 1) ? 0x0c0c0302u : 0x0c0c0100u);
-            const uint32_t up = xl_row_shr1(let);
-            let = l == 0 ? nl : up;
+            // (one v_perm_b32 with a per-lane selector: the first lane picks its two bytes of the pair, the others the lane above's letters)
+            let = pk_perm(xl_row_shr1(let), (u & 2) ? pairB : pairA, (u & 1) ? lsel1 : lsel0);
             const uint32_t tab0 = *(const uint32_t *)(lds + (let & 0xFFu)), tab1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
             // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
             const pk16 vH = xl_row_shr1(Hl_old) & nz;
@@ -1493,7 +1495,9 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
             Hl_cur = H[SA - 1];
             pm = cmx;
             if (!REV && l == W - 1 && t >= W - 1) {              // column t-7 is complete
-                if (mc_lds) maxcol[(t - (W - 1)) * G + g] = pm; else store_global_u32(maxcol + ((t - (W - 1)) * G + g), pm);
+                // (both addresses spelled out -- LDS behind the table, or this block's scratch: a step then costs no address arithmetic)
+                const uint32_t idx = (uint32_t)((t - (W - 1)) * G + g);
+                if (mc_lds) ((uint32_t *)(IPX_LDS_BASE + 128))[idx] = pm; else store_global_u32(maxcol + idx, pm);
             }
             // -- this lane's best (ssw.c:521-539, per lane; non-negative halves order like integers)
             const pk16 nb = pk_max(lbest, cmx);
