@@ -1431,18 +1431,6 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
 
     int tend = -1;                                              // (reverse) step at which every read has passed its last column
     for (int t0 = 0; t0 < TT && (tend < 0 || t0 < tend); t0 += 4) {
-        if (t0 > 0) {
-            IPX_UNROLL
-            for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
-            IPX_VMEM_FENCE();
-            IPX_UNROLL
-            for (int h = 0; h < 2; ++h) {
-                int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 1) : (t0 >> 2) + 1;
-                if (k < 0) k = 0;
-                if (k > kmax[h]) k = kmax[h];
-                nxt[h] = load_global_u32(refw[h] + k);
-            }
-        }
         if (REV && tend < 0) {
             // A lane that holds the score the pass must reach got it in a column at or after the read's first such column,
             // W-1 steps at most before every lane has been through that column: seen here, the read needs 7 more steps.
@@ -1521,6 +1509,20 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
                 }
             }
             ccol = pk_add(ccol, 0x00010001u);
+        }
+        // the next group's letters have arrived (requested a group ago); request those of the group after it.  (At the END of the body,
+        // unconditionally: requested at the top under "not the first group", the compiler copied the loaded word into the loop's
+        // register at once and every group waited for its own request.)
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
+        IPX_VMEM_FENCE();
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            // (unsigned, one minimum: the word index costs the vector ALU a v_min and the 64-bit address add, nothing else)
+            int kr = (idx0[h] >> 2) - ((t0 >> 2) + 2);
+            if (kr < 0) kr = 0;
+            const uint32_t k = REV ? (uint32_t)kr : (uint32_t)((t0 >> 2) + 2);
+            nxt[h] = load_global_u32(refw[h] + (k < (uint32_t)kmax[h] ? k : (uint32_t)kmax[h]));
         }
     }
 
