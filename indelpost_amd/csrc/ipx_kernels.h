@@ -491,8 +491,11 @@ IPX_HD constexpr int ipx_dp_perm_waves(int smax)
     const int w = 512 / (4 * smax + 90);
     return w < 1 ? 1 : w;
 }
-template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false, bool F16 = false, bool VL2 = false>
-IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow)
+// (the body is a function of the block's rank among the blocks working on these classes: the kernel below passes its block id,
+//  k_dp_pass_tier the rank it computes per class)
+template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM, bool F16, bool VL2>
+IPX_DEV void dp_pass_body(const IpxBatch &b, const IpxPlan &p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow,
+                          const uint32_t rank, const uint32_t nrank)
 {
     constexpr bool LOW = STAGE == IPX_STAGE_LOW, HIGH = STAGE == IPX_STAGE_HIGH;
     static_assert(STAGE == IPX_STAGE_EXACT || ((W == 16 || VL2) && !REV), "the bracket stages exist for the 8-bit forward pass");
@@ -533,7 +536,7 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
     // skipping the foreign ones (as an earlier version did) cost each block thousands of class look-ups.
     int own_cls = cls_lo;                                             // (sweep) class reached by the walk
     uint32_t own_base = 0;                                            // (sweep) owned tiles in the classes before own_cls
-    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
+    for (uint32_t want = rank;; want += nrank) {
         // ---- locate the tile: class (= segLen), first slot in perm, number of reads -------------
         int cls;
         uint32_t tile;
@@ -1260,6 +1263,52 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
         }
     }
 }
+template <int W, int SMAX, bool REV, bool EXACT, int STAGE, bool PERM = false, bool F16 = false, bool VL2 = false>
+IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k_dp_pass(IpxBatch b, IpxPlan p, int cls_lo, int cls_hi, int maxcols, int pass, uint64_t skip_fast, uint64_t skip_slow)
+{
+    dp_pass_body<W, SMAX, REV, EXACT, STAGE, PERM, F16, VL2>(b, p, cls_lo, cls_hi, maxcols, pass, skip_fast, skip_slow, (uint32_t)IPX_BID, (uint32_t)IPX_GDIM);
+}
+
+// a function body as a CALL (tier kernels): inlined, the bodies of a tier share one register allocation and the longest one's spills
+// land in all of them; called, each keeps the allocation of its stand-alone kernel (the batch and plan descriptors then travel by
+// reference, i.e. through private memory)
+#if defined(IPX_CPU_EMU)
+#define IPX_NOINLINE_DEV static
+#else
+#define IPX_NOINLINE_DEV __device__ __attribute__((noinline))
+#endif
+
+// k_dp_pass_tier (r03): the STEPPED 8-bit passes (exact stage, forward and reverse; selector profile, fast gaps) of the classes
+// SLO..SHI in ONE launch.  What reaches these passes is what the proofs leave open: a few thousand reads of one class, eight of
+// another, none of most -- and every class had a launch of its own, each lasting as long as ONE tile takes (0.2-0.7 ms: hundreds of
+// columns, a hundred-odd dependent instructions each), one after the other on the stream.  Here block b takes the b-th tile of
+// the concatenated tile lists of the launch's classes (grid = the number of tiles the previous run of the context saw), so the
+// tiles of all classes are in flight together and the launch lasts as long as its longest tile.
+#define IPX_PASS_TIER_LO 1                      // classes the launch covers (8-bit segLen: reads of up to 256 bp)
+#define IPX_PASS_TIER_HI 16
+template <int W, int S, bool REV, int STAGE>
+IPX_NOINLINE_DEV void dp_pass_body_call(const IpxBatch &b, const IpxPlan &p, int maxcols, int pass, uint32_t rank, uint32_t nrank)
+{
+    dp_pass_body<W, S, REV, true, STAGE, true, false, false>(b, p, S, S, maxcols, pass, (uint64_t)0, (uint64_t)0, rank, nrank);
+}
+template <int W, int SLO, int SHI, bool REV, int STAGE>
+IPX_DEV void dp_pass_tier_walk(uint32_t set_mask, const IpxBatch &b, const IpxPlan &p, int maxcols, int pass, uint32_t base)
+{
+    if constexpr (SLO <= SHI) {
+        if ((set_mask >> SLO) & 1u) {
+            const uint32_t n = p.tile_off[SLO + 1] - p.tile_off[SLO], nb = (uint32_t)IPX_GDIM;
+            const uint32_t rank = ((uint32_t)IPX_BID + nb - base % nb) % nb;      // this block's rank for the class: its tiles follow the classes before it
+            if (rank < n) dp_pass_body_call<W, SLO, REV, STAGE>(b, p, maxcols, pass, rank, nb);
+            base += n;
+        }
+        dp_pass_tier_walk<W, SLO + 1, SHI, REV, STAGE>(set_mask, b, p, maxcols, pass, base);
+    }
+}
+template <int W, int SLO, int SHI, bool REV, int STAGE>
+IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SHI) : 1) void k_dp_pass_tier(IpxBatch b, IpxPlan p, uint32_t set_mask, int maxcols, int pass)
+{
+    dp_pass_tier_walk<W, SLO, SHI, REV, STAGE>(set_mask, b, p, maxcols, pass, 0u);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_dp_skew: the 16-bit passes (exact segLen, selector profile, half precision: see k_dp_pass PERM / F16) as a WAVEFRONT
@@ -1642,11 +1691,6 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
 // (tier kernels) the tile body as a CALL: inlined, the bodies of a tier share one register allocation and the longest one's spills
 // land in all of them; called, each keeps the allocation of its stand-alone kernel (the batch and plan descriptors travel by
 // reference, i.e. through private memory -- they are read in the tile's set-up and finalisation only, never in the column loop)
-#if defined(IPX_CPU_EMU)
-#define IPX_NOINLINE_DEV static
-#else
-#define IPX_NOINLINE_DEV __device__ __attribute__((noinline))
-#endif
 template <int SMAX, bool REV, int BH>
 IPX_NOINLINE_DEV void dp_skew_tile_call(const IpxBatch &b, const IpxPlan &p, const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
                                         unsigned char *lds, const uint32_t nz)
@@ -2925,7 +2969,11 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_TIER_EXTERN(LO, HI, REV, BH) extern template __global__ void k_dp_skew_tier<LO, HI, REV, BH> IPX_TIER_SIG;
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
+// the stepped 8-bit passes of classes 1..16 in one launch (k_dp_pass_tier)
+#define IPX_PASS_TIER_DEFINE(REV) template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
+#define IPX_PASS_TIER_EXTERN(REV) extern template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #if defined(IPX_EXTERN_KERNELS)
+IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
 IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 1) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 2) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, true, 2)
 IPX_TIER_WORD(IPX_TIER_EXTERN, false) IPX_TIER_WORD(IPX_TIER_EXTERN, true) IPX_TIER_BYTE(IPX_TIER_EXTERN, false) IPX_TIER_BYTE(IPX_TIER_EXTERN, true)

@@ -114,6 +114,7 @@ static inline bool ipx_low2_ok(const IpxBatch &b, const IpxDims &d, int routing)
 #define IPX_NUM_KEYS (IPX_K_NUM * 256)
 #define IPX_SUB_GENERIC 140
 #define IPX_SUB_LONG 141      // k_dp_long (reads of 64 segments or more)
+#define IPX_SUB_TIER 150      // timing sub-key of tier t: IPX_SUB_TIER + t (wavefront tiers 0..3; 8 = the stepped 8-bit tier, k_dp_pass_tier)
 
 template <class BE, int W, bool REV, int STAGE>
 static void ipx_launch_dp_class(BE &be, const IpxBatch &b, const IpxPlan &p, int cls, int maxcols, int kclass, int pass, int routing)
@@ -206,8 +207,25 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
         int top = -1;
         for (int c = 0; c <= IPX_MAX_SEG; ++c) if (hs[c]) top = c;
         if (top >= IPX_MAX_SEG) lng = true;
+        uint32_t tier = 0;                                        // classes that share the tier launch (k_dp_pass_tier) instead of having their own
+        if constexpr (W == 16 && STAGE == IPX_STAGE_EXACT) {
+            if (half == 0 && ipx_perm_profile_ok(b.mat, routing) && !(routing & IPX_ROUTE_NO_TIERS)) {
+                int n = 0;
+                for (int c = from > IPX_PASS_TIER_LO ? from : IPX_PASS_TIER_LO; c <= top && c <= IPX_PASS_TIER_HI; ++c)
+                    if (REV ? (hs[c] || (c + 1 <= top && hs[c + 1])) : hs[c] != 0) { tier |= 1u << c; ++n; }
+                if (n < 2) tier = 0;
+            }
+            if (tier) {
+                const int key = IPX_KEY(kclass, IPX_SUB_TIER + 8);
+                be.note_dp_set(key, pass, 0, tier, 8);
+                be.launch(key, k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>, be.dp_grid_set(pass, 0, tier), 64,
+                          ipx_dp_lds_bytes(W, IPX_PASS_TIER_HI, REV, maxcols, true, routing), b, p, tier, maxcols,
+                          pass | (ipx_dp_mc_in_lds(W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0));
+            }
+        }
         for (int c = from; c <= top && c <= IPX_MAX_EXACT; ++c) {
             const bool own = REV ? (hs[c] || (c + 1 <= top && hs[c + 1])) : hs[c] != 0;
+            if (own && ((tier >> (c < 32 ? c : 31)) & 1u) && c < 32) { exact[half] |= 1ull << c; continue; }
             if (own) { exact[half] |= 1ull << c; ipx_launch_dp_class<BE, W, REV, STAGE>(be, b, p, c + half * IPX_SLOW_BASE, maxcols, kclass, pass, routing); }
         }
         for (int c = from; c <= top && c < IPX_MAX_SEG; ++c)
@@ -246,7 +264,6 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
 // BH = 1 / 2: the plain recurrence in the 8-bit dialect, class c (8-bit segLen) = 2c segments of the 8-lane layout.  A launch also serves
 // the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).  The classes of `set` that fall into one occupancy
 // tier share ONE launch (k_dp_skew_tier) when there are at least two of them; a class alone in its tier keeps its own kernel.
-#define IPX_SUB_TIER 150      // timing sub-key of tier t: IPX_SUB_TIER + t
 template <class BE, bool REV, int BH>
 static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing)
 {
