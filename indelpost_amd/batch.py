@@ -106,20 +106,38 @@ class JobTable:
         tables = list(tables)
         if not tables:
             return cls(np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int32), 0, 0)
-        nj = np.fromiter((t.n_jobs for t in tables), np.int64, len(tables))
-        nr = np.fromiter((t.n_refs for t in tables), np.int64, len(tables))
-        rbytes = np.fromiter((int(t.read_off[-1]) for t in tables), np.int64, len(tables))
-        fbytes = np.fromiter((int(t.ref_off[-1]) for t in tables), np.int64, len(tables))
-        rbase, fbase, wbase = np.cumsum(rbytes) - rbytes, np.cumsum(fbytes) - fbytes, np.cumsum(nr) - nr
-        read_off = np.zeros(int(nj.sum()) + 1, np.int64)
-        read_off[1:] = np.concatenate([t.read_off[1:] for t in tables]) + np.repeat(rbase, nj)
-        ref_off = np.zeros(int(nr.sum()) + 1, np.int64)
-        ref_off[1:] = np.concatenate([t.ref_off[1:] for t in tables]) + np.repeat(fbase, nr)
-        ref_id = np.concatenate([t.ref_id for t in tables]) + np.repeat(wbase, nj).astype(np.int32)
-        masks = [t.mask_len for t in tables]
-        mask = np.concatenate(masks) if all(m is not None for m in masks) else None
-        return cls(np.concatenate([t.reads[:t.read_off[-1]] for t in tables]), read_off, np.concatenate([t.refs[:t.ref_off[-1]] for t in tables]),
-                   ref_off, ref_id, np.concatenate([t.gap_open for t in tables]), np.concatenate([t.gap_ext for t in tables]), mask)
+        # ONE Python pass over the tables (attribute reads and list appends only); everything else is whole-array arithmetic
+        ro, fo, rid, go, ge, rd, rf, mk = [], [], [], [], [], [], [], []
+        for t in tables:
+            ro.append(t.read_off); fo.append(t.ref_off); rid.append(t.ref_id); go.append(t.gap_open)
+            ge.append(t.gap_ext); rd.append(t.reads); rf.append(t.refs); mk.append(t.mask_len)
+        n = len(tables)
+
+        def offsets(parts, payload):
+            """concatenated offset arrays (each starts at 0) -> one offset array; the payload arrays cut to what the offsets cover"""
+            cnt = np.fromiter(map(len, parts), np.int64, n)              # entries + 1 per table
+            allo = np.concatenate(parts)
+            ends = np.cumsum(cnt)
+            size = allo[ends - 1]                                        # bytes per table
+            base = np.cumsum(size) - size
+            keep = np.ones(len(allo), bool)
+            keep[ends - cnt] = False                                     # every table's leading 0
+            out = np.empty(len(allo) - n + 1, np.int64)
+            out[0] = 0
+            np.add(allo[keep], np.repeat(base, cnt - 1), out=out[1:])
+            have = np.fromiter(map(len, payload), np.int64, n)
+            if not np.array_equal(have, size):                           # (arrays longer than their offsets say: cut them)
+                payload = [a[:k] for a, k in zip(payload, size.tolist())]
+            return out, np.concatenate(payload), cnt - 1
+
+        read_off, reads, nj = offsets(ro, rd)
+        ref_off, refs, nr = offsets(fo, rf)
+        ref_id = np.concatenate(rid)
+        if ref_id.dtype != np.int32:
+            ref_id = ref_id.astype(np.int32)
+        ref_id = ref_id + np.repeat((np.cumsum(nr) - nr).astype(np.int32), nj)
+        mask = np.concatenate(mk) if all(m is not None for m in mk) else None
+        return cls(reads, read_off, refs, ref_off, ref_id, np.concatenate(go), np.concatenate(ge), mask)
 
     def shard(self, lo, hi):
         """Contiguous job range [lo, hi) with only the windows it references."""
