@@ -417,6 +417,10 @@ def test_emu_rare_classes_ride_along_and_tiers_share_a_launch(emu, oracle_mod, p
         else:
             assert tier(a0, K_BYTE_PLAIN) and not tier(a1, K_BYTE_PLAIN)
             assert (base.records["mode"] == 0).all()
+            # the stepped 8-bit passes (what the proofs leave open, slow gaps aside): ONE launch for the classes 1..16 (k_dp_pass_tier,
+            # timing sub-key 158) instead of one per class; stand-alone launches again with the tiers switched off
+            assert 158 in tier(a0, K_BYTE_EXACT) and 158 in tier(a0, K_BYTE_REV)
+            assert not tier(a1, K_BYTE_EXACT) and len(_launched(a1, K_BYTE_EXACT)) > len(_launched(a0, K_BYTE_EXACT))
 
 
 def test_emu_long_reads_take_the_long_read_kernel(emu, oracle_mod, port):
