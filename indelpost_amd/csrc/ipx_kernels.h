@@ -2080,14 +2080,15 @@ IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd,
                 e = e1 > e2 ? e1 : e2;
                 if (e < 0) e = 0;
             }
-            int hm = Hf[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
+            // (a cell outside the window, letter 7, scores 0 -- bytes 5..7 of a table entry -- and needs no special case: left of the
+            //  window everything a cell sees is 0 and stays 0; right of it whatever a cell holds never comes back, moves go right and down)
+            int hm = Hf[k] + (int)(int8_t)(row >> (8 * cl));
             if (hm < e) hm = e;
             if (hm < 0) hm = 0;
             int hf, fk;
             if (!cross) { if (hm < f) hm = f; hf = hm; fk = f; }
             else { hf = hm > f ? hm : f; fk = 0; }
-            if (cl > 4u) { hm = 0; hf = 0; e = 0; fk = 0; }   // outside the window
-            if (hf >= cap) proven = true;
+            if (hf >= cap && cl <= 4u) proven = true;
             Hm[k] = hm; Hf[k] = hf; F[k] = fk; hleft = hm;
         }
         const int cn = rr + 1 + d0 + HB;                   // column entering the band on the next row
@@ -2283,13 +2284,12 @@ IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const 
                 e = e1 > e2 ? e1 : e2;
                 if (e < 0) e = 0;
             }
-            int hm = Hf[k] + (int)(int8_t)(row >> (8 * (cl > 4u ? 0u : cl)));
+            int hm = Hf[k] + (int)(int8_t)(row >> (8 * cl));        // (outside the window: score 0, no special case -- see prove_band)
             if (hm < e) hm = e;
             if (hm < 0) hm = 0;
             int hf, fk;
             if (!cross) { if (hm < f) hm = f; hf = hm; fk = f; }      // inside a segment: the main loop's own F
             else { hf = hm > f ? hm : f; fk = 0; }                   // first row of a segment: lazy-F's first step, a final value only
-            if (cl > 4u) { hm = 0; hf = 0; e = 0; fk = 0; }          // outside the window
             Hm[k] = hm; Hf[k] = hf; F[k] = fk; hleft = hm;
             if (t.e2 >= 0 && cl <= 4u) {
                 if (c == t.e2 && hf > w2) w2 = hf;
