@@ -2401,8 +2401,35 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
 // register/LDS-resident kernel k_tb_fast<BW> (list BW-1 = lists + (BW-1)*n_jobs, counter BW-1), wider
 // ones straight to the general kernel (list 7 = `esc`, counter 7).
 #define IPX_TBF_MAXBW 7
-IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc, int all_general)
+// r03, UNGAPPED alignments: when refLen == readLen (first band 1) and the scores on the rectangle's diagonal add up to score1, the
+// CIGAR is one run of M and banded_sw's DP is not needed to know it.  Why: every value of banded_sw's matrix is the score of a local
+// alignment inside the rectangle (floors at 0, ssw.c:655-656), hence <= score1, the optimum.  Were H at some diagonal cell larger than
+// the diagonal's prefix sum there, continuing along the diagonal would end above score1; so H equals the prefix sum on the whole
+// diagonal, the band of width 1 reaches score1 (no doubling, ssw.c:669), at every diagonal cell the gap candidates are <= the diagonal
+// one and ties go to the diagonal (ssw.c:663), and the walk back from the corner (ssw.c:673-733) never leaves it: (n)M by the tail rule
+// (ssw.c:734-751).  The job gets that CIGAR here and appears in no traceback list.  (A prefix sum cannot be negative either: dropping
+// the prefix would beat the optimum.)
+IPX_DEV bool tb_ungapped(const IpxBatch &b, const IpxResult &r, int64_t i, int n, const uint64_t *coltab)
 {
+    const int8_t *rd = b.reads + b.read_off[i] + r.read_begin1;
+    const int8_t *rf = b.refs_packed + b.refp_off[b.ref_id[i]] + r.ref_begin1;
+    int u = 0;
+    for (int k = 0; k < n; ++k) {
+        int a = rd[k];
+        if ((unsigned)a > 4u) a = 4;
+        u += (int)(int8_t)(coltab[a] >> (8 * (unsigned)(uint8_t)rf[k]));
+    }
+    return u == (int)r.score1;
+}
+IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc, int all_general, int ungapped)
+{
+    uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
+    if (IPX_TID < 5) {
+        uint64_t t = 0;
+        for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + IPX_TID] << (8 * c);
+        coltab[IPX_TID] = t;
+    }
+    IPX_SYNC();
     const int64_t chunk = (int64_t)IPX_BDIM * IPX_PLAN_ROUNDS, stride = (int64_t)IPX_GDIM * chunk;
     const int64_t iters = (b.n_jobs + stride - 1) / stride;
     for (int64_t q = 0; q < iters; ++q) {                  // every lane runs every iteration (wave-wide ballots)
@@ -2413,11 +2440,22 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
             const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)k * IPX_BDIM + IPX_TID;
             cls[k] = -1;
             if (i < b.n_jobs) {
-                const IpxResult r = b.res[i];
+                IpxResult r = b.res[i];
                 if (cigar_needed(b, r)) {
                     const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
                     const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
                     cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : IPX_TBF_MAXBW;   // (all_general: a small batch, one wave per job)
+                    if (ungapped && bw == 1 && readLen > 0 && r.ref_begin1 >= 0 && r.read_begin1 >= 0 && tb_ungapped(b, r, i, readLen, coltab)) {
+                        const uint32_t off = atomic_add_u32(b.cigar_cursor, 1u);
+                        if (off + 1u > b.cigar_cap) atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL);
+                        else {
+                            b.cigar_pool[off] = (uint32_t)readLen << 4;                        // (n)M
+                            r.cigar_off = off;
+                            r.cigar_len = 1;
+                            b.res[i] = r;
+                        }
+                        cls[k] = -1;
+                    }
                 }
             }
         }

@@ -85,6 +85,7 @@ enum {
     IPX_ROUTE_NO_EXACT_DIRECT = 2048, // a read the proofs leave open takes the lower-bound stage before the stepped one (r03 first half) instead of
                                       //   the stepped pass at once (which steps only where a cut can happen and costs little more than the lower bound)
     IPX_ROUTE_TB_NO_WAVE_PER_JOB = 4096,  // small batches too take the lane-per-job traceback kernels (default: up to 2048 jobs, one wave per job)
+    IPX_ROUTE_TB_NO_UNGAPPED = 8192,      // every CIGAR through banded_sw's DP (default: an alignment whose diagonal alone reaches score1 gets its one-run CIGAR from k_tb_list)
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 

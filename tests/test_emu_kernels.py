@@ -157,7 +157,8 @@ def test_emu_explicit_mask_len(emu, oracle_mod, port):
 @pytest.mark.parametrize("knobs", [(R.ROUTE_NO_BRACKET,), (R.ROUTE_NO_PERM_PROFILE, R.ROUTE_TB_NO_FUSE, R.ROUTE_TB_NO_WAVE_PER_JOB), (R.ROUTE_NO_MC_LDS, R.ROUTE_TB_NO_FUSE),
                                    (R.ROUTE_NO_WORD_FIRST, R.ROUTE_NO_BRACKET, R.ROUTE_NO_PERM_PROFILE), (R.ROUTE_NO_PLAIN_FIRST,),
                                    (R.ROUTE_NO_CLASS_MERGE,), (R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_VL2), (R.ROUTE_NO_EXACT_DIRECT,),
-                                   (R.ROUTE_TB_NO_WAVE_PER_JOB,), (R.ROUTE_TB_NO_WAVE_PER_JOB, R.ROUTE_TB_NO_FUSE, R.ROUTE_NO_MC_LDS)])
+                                   (R.ROUTE_TB_NO_WAVE_PER_JOB,), (R.ROUTE_TB_NO_WAVE_PER_JOB, R.ROUTE_TB_NO_FUSE, R.ROUTE_NO_MC_LDS), (R.ROUTE_TB_NO_UNGAPPED,),
+                                   (R.ROUTE_TB_NO_UNGAPPED, R.ROUTE_TB_NO_WAVE_PER_JOB)])
 def test_emu_routing_knobs_off(emu, golden_c, knobs):
     """The speed-only routing decisions (the upper-bound stage, 16-bit pass first, register-selector profile, column
     maxima in LDS, fused traceback launch) must not change any result: golden vectors with each turned off."""

@@ -69,7 +69,8 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True, fast_gaps_only=False):
                                            ((3, 2), (R.ROUTE_NO_F16,)), ((3, 2), (R.ROUTE_NO_SKEW,)), ((3, 2), (R.ROUTE_NO_VL2, "fast_gaps")), ((3, 2), ("fast_gaps", "vl2")), ((1, 1), ("fast_gaps", "vl2")), ((5, 4), (R.ROUTE_NO_SKEW, "fast_gaps")), ((7, 8), ("fast_gaps",)), ((6, 5), ()), ((8, 1), ("fast_gaps",)),
                                            ((3, 2), (R.ROUTE_NO_PLAIN_FIRST, "fast_gaps")), ((1, 1), (R.ROUTE_NO_PLAIN_FIRST,)), ((3, 2), (R.ROUTE_NO_CLASS_MERGE,)),
                                            ((1, 1), (R.ROUTE_NO_CLASS_MERGE, "fast_gaps")), ((2, 2), (R.ROUTE_NO_VL2, "fast_gaps")),
-                                           ((3, 2), (R.ROUTE_NO_EXACT_DIRECT, "fast_gaps")), ((1, 1), (R.ROUTE_NO_EXACT_DIRECT,)), ((2, 2), (R.ROUTE_NO_TIERS,))])
+                                           ((3, 2), (R.ROUTE_NO_EXACT_DIRECT, "fast_gaps")), ((1, 1), (R.ROUTE_NO_EXACT_DIRECT,)), ((2, 2), (R.ROUTE_NO_TIERS,)),
+                                           ((3, 2), (R.ROUTE_TB_NO_UNGAPPED,)), ((1, 3), (R.ROUTE_TB_NO_UNGAPPED, "fast_gaps"))])
 def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd):
     from oracle.oracle import cpu_batch_results, fnv1a_ops
     fast = "fast_gaps" in knobs
