@@ -2017,8 +2017,10 @@ IPX_KERNEL_WAVE void k_dp_long(IpxBatch b, IpxPlan p, int na, int maxcols, int p
 #define IPX_PROVE_BAND 15
 #define IPX_PROVE_BAND_NARROW 5                 // r03: a band of 5 diagonals first (most reads with an indel stay within 2 of the end diagonal), 15 for the rest
 #define IPX_PROVE_CHUNK 4                       // blocks of 64 consecutive jobs whose still-unproven reads share the band rounds
-// LDS: 64 B score columns | 64 * IPX_PROVE_CHUNK queue entries | read staging (lds_cap bytes)
-static inline int ipx_prove_lds_bytes(int lds_cap) { return 64 + 256 * IPX_PROVE_CHUNK + lds_cap; }
+// LDS: 64 B score columns | narrow-band queue (64 * IPX_PROVE_CHUNK + 64 jobs) | wide-band queue (128 jobs) | read staging (lds_cap bytes)
+#define IPX_PROVE_QA (64 * IPX_PROVE_CHUNK + 64)
+#define IPX_PROVE_QB 128
+static inline int ipx_prove_lds_bytes(int lds_cap) { return 64 + 4 * (IPX_PROVE_QA + IPX_PROVE_QB) + lds_cap; }
 
 // ungapped test: best run on the diagonal through the 16-bit end point (rd = the read's letters)
 IPX_DEV bool prove_ungapped(const IpxBatch &b, const IpxResult &r, const int8_t *rd, const int8_t *rf)
@@ -2103,13 +2105,15 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
 {
     // 64 consecutive jobs per round: their reads are contiguous in HBM, so the wave copies them into LDS with coalesced loads
     // and every lane then walks its own read there (the per-lane backwards byte walk straight from HBM fetched ~6 KB per
-    // read).  The ungapped test settles about half of the reads; a wave that ran the band for the other half with half its
-    // lanes idle would gain nothing, so the jobs still open after IPX_PROVE_CHUNK rounds are queued in LDS and the band
-    // runs on full waves of them (r02: 4 band rounds per 256 jobs -> 2 on config 2b; chunk_blocks rounds, host's choice).
+    // read).  The ungapped test settles about half of the reads.  The others are QUEUED in LDS and the bands run on full waves of
+    // them: a narrow band first, the wide one for what it leaves open.  Both queues carry over from chunk to chunk of the wave's
+    // walk (r03: a band round runs as soon as 64 jobs wait for it, and once at the end for the remainder; before, every chunk of
+    // 256 jobs ran its own rounds, the wide one with a dozen lanes busy).
     const int lane = lane_id();
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
-    uint32_t *queue = (uint32_t *)(IPX_LDS_BASE + 64);             // jobs (index inside the chunk) waiting for the band
-    int8_t *stage = (int8_t *)IPX_LDS_BASE + 64 + 256 * IPX_PROVE_CHUNK;
+    uint32_t *qa = (uint32_t *)(IPX_LDS_BASE + 64);                // jobs waiting for the narrow band
+    uint32_t *qb = qa + IPX_PROVE_QA;                              // jobs waiting for the wide band
+    int8_t *stage = (int8_t *)(qb + IPX_PROVE_QB);
     if (lane < 5) {
         uint64_t t = 0;
         for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
@@ -2118,9 +2122,51 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
     const int64_t nb = (b.n_jobs + 63) / 64;
     const int CB = chunk_blocks < 1 ? 1 : chunk_blocks > IPX_PROVE_CHUNK ? IPX_PROVE_CHUNK : chunk_blocks;   // (small batches: 1, for latency)
     const int64_t nchunk = (nb + CB - 1) / CB;
+    uint32_t na = 0, nw = 0;                                       // queued jobs (the same in every lane)
+    // one band round over cnt <= 64 queue entries starting at q[first]; wide = false: what the narrow band leaves open goes to qb
+    auto band_round = [&](const uint32_t *q, uint32_t first, uint32_t cnt, bool wide) {
+        IPX_SYNC();                                                // queue entries written; the staging area is free
+        const bool mine = (uint32_t)lane < cnt;
+        const int64_t i = mine ? (int64_t)q[first + lane] : 0;
+        int key = -1;
+        bool open = false;
+        if (mine) {
+            IpxResult r = b.res[i];
+            const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+            const int8_t *rd = b.reads + b.read_off[i];           // straight from HBM: one letter per band row, requested a row ahead
+            const int rid = b.ref_id[i];
+            const int8_t *rf = b.refs_packed + b.refp_off[rid];
+            const bool proven = wide ? prove_band<IPX_PROVE_BAND>(b, r, rd, rf, Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab)
+                                     : prove_band<IPX_PROVE_BAND_NARROW>(b, r, rd, rf, Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
+            if (!proven && !wide) open = true;
+            else {
+                // not proven: the 8-bit pass decides.  A read that could score well beyond the threshold (1.5 x) most likely does overflow:
+                // the lower-bound stage at 16 reads per wave sees that soonest; a borderline read most likely does not: the stepped pass at once
+                const bool likely = 2 * Lr * b.max_match >= 3 * (255 - b.bias);
+                r.mode = proven ? IPX_MODE_WORD : ((b.exact_direct && !likely) ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
+                b.res[i] = r;
+                key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
+            }
+        }
+        plan_note(b, key);
+        if (!wide) {
+            const uint64_t om = xl_ballot(open);
+            if (open) qb[nw + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            nw += (uint32_t)__builtin_popcountll(om);
+        }
+    };
+    // run the rounds that are full (all = false) or everything that waits (all = true: the wave's last chunk is done)
+    auto drain = [&](bool all) {
+        while (na >= 64u || (all && na > 0u)) {
+            const uint32_t cnt = na < 64u ? na : 64u;
+            band_round(qa, na - cnt, cnt, false);                  // (from the tail: nothing moves)
+            na -= cnt;
+            while (nw >= 64u) { band_round(qb, nw - 64u, 64u, true); nw -= 64u; }
+        }
+        while (all && nw > 0u) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, true); nw -= cnt; }
+    };
     for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
         const int64_t cbase = chunk * CB * 64;
-        uint32_t qn = 0;                                           // queued jobs (the same in every lane)
         for (int sb = 0; sb < CB; ++sb) {
             const int64_t i0 = cbase + (int64_t)sb * 64, i = i0 + lane;
             if (i0 >= b.n_jobs) break;
@@ -2146,47 +2192,12 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
             }
             plan_note(b, key);
             const uint64_t om = xl_ballot(open);
-            if (open) queue[qn + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
-            qn += (uint32_t)__builtin_popcountll(om);
+            if (open) qa[na + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            na += (uint32_t)__builtin_popcountll(om);
         }
-        // band rounds over the queue: the narrow band first; what it leaves open is queued again (in place: entries are written
-        // behind the ones being read) for the wide band, whose verdict stands
-        for (int round = 0; round < 2; ++round) {
-            uint32_t qnext = 0;
-            for (uint32_t q0 = 0; q0 < qn; q0 += 64) {
-                IPX_SYNC();                                        // queue entries written; the staging area is free
-                const bool mine = q0 + (uint32_t)lane < qn;
-                const int64_t i = mine ? cbase + (int64_t)queue[q0 + lane] : 0;
-                int key = -1;
-                bool open = false;
-                if (mine) {
-                    IpxResult r = b.res[i];
-                    const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
-                    const int8_t *rd = b.reads + b.read_off[i];   // straight from HBM: one letter per band row, requested a row ahead
-                    const int rid = b.ref_id[i];
-                    const int8_t *rf = b.refs_packed + b.refp_off[rid];
-                    const bool proven = round == 0 ? prove_band<IPX_PROVE_BAND_NARROW>(b, r, rd, rf, Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab)
-                                                   : prove_band<IPX_PROVE_BAND>(b, r, rd, rf, Lr, b.ref_len[rid], b.gap_open[i], b.gap_ext[i], coltab);
-                    if (!proven && round == 0) open = true;
-                    else {
-                        // not proven: the 8-bit pass decides.  A read that could score well beyond the threshold (1.5 x) most likely does overflow:
-                        // the lower-bound stage at 16 reads per wave sees that soonest; a borderline read most likely does not: the stepped pass at once
-                        const bool likely = 2 * Lr * b.max_match >= 3 * (255 - b.bias);
-                        r.mode = proven ? IPX_MODE_WORD : ((b.exact_direct && !likely) ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
-                        b.res[i] = r;
-                        key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
-                    }
-                }
-                plan_note(b, key);
-                if (round == 0) {
-                    const uint64_t om = xl_ballot(open);
-                    if (open) queue[qnext + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
-                    qnext += (uint32_t)__builtin_popcountll(om);
-                }
-            }
-            qn = qnext;
-        }
+        drain(false);
     }
+    drain(true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2311,7 +2322,8 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
 {
     const int lane = lane_id();
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
-    uint32_t *queue = (uint32_t *)(IPX_LDS_BASE + 64);             // jobs (index inside the chunk) waiting for the band
+    uint32_t *qa = (uint32_t *)(IPX_LDS_BASE + 64);                // jobs waiting for the narrow band
+    uint32_t *qb = qa + IPX_PROVE_QA;                              // jobs waiting for the wide band
     if (lane < 5) {
         uint64_t tt = 0;
         for (int c = 0; c < 5; ++c) tt |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
@@ -2321,67 +2333,78 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
     const int64_t nb = (b.n_jobs + 63) / 64;
     const int CB = chunk_blocks < 1 ? 1 : chunk_blocks > IPX_PROVE_CHUNK ? IPX_PROVE_CHUNK : chunk_blocks;
     const int64_t nchunk = (nb + CB - 1) / CB;
-    for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
-        const int64_t cbase = chunk * CB * 64;
-        uint32_t qn = 0;                                           // queued jobs (the same in every lane)
-        for (int round = 0; round < 3; ++round) {
-            // round 0: every job of the chunk, ungapped test, the rest queued; round 1: the queue, narrow band, the rest queued again (in
-            // place: entries are written behind the ones being read); round 2: the queue, wide band
-            const uint32_t total = round == 0 ? (uint32_t)(CB * 64) : qn;
-            uint32_t qnext = 0;
-            if (round >= 1) IPX_SYNC();                            // queue entries written
-            for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-                int64_t i = -1;
-                if (round == 0) { const int64_t ii = cbase + q0 + lane; if (ii < b.n_jobs) i = ii; }
-                else if (q0 + (uint32_t)lane < qn) i = cbase + (int64_t)queue[q0 + lane];
-                int key = -1;
-                bool open = false;
-                if (i >= 0) {
-                    IpxResult r = b.res[i];
-                    const bool mine = REV ? r.mode == IPX_MODE_NEED_REV_PROOF : (r.mode == IPX_MODE_NEED_FWD_PROOF || r.mode == IPX_MODE_NEED_FWD_PROOF2);
-                    if (mine) {
-                        const int rid = b.ref_id[i];
-                        const int8_t *rd = b.reads + b.read_off[i];
-                        const int8_t *rf = b.refs_packed + b.refp_off[rid];
-                        const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
-                        IpxProveTarget t;
-                        if (!REV) {
-                            t.Lp = Lr; t.ncols = b.ref_len[rid]; t.r1 = r.read_end1; t.c1 = r.ref_end1; t.v1 = r.score1;
-                            t.e2 = r.mode == IPX_MODE_NEED_FWD_PROOF2 ? r.ref_end2 : -1; t.s2 = r.score2;
-                        } else {
-                            t.Lp = r.read_end1 + 1; t.ncols = r.ref_end1 + 1; t.r1 = r.read_end1 - r.read_begin1; t.c1 = r.ref_end1 - r.ref_begin1;
-                            t.v1 = r.score1; t.e2 = -1; t.s2 = 0;
-                        }
-                        const bool sane = t.r1 >= 0 && t.r1 < t.Lp && t.c1 >= 0 && t.c1 < t.ncols;
-                        bool ok = false, decided = true;
-                        if (sane) {
-                            if (round == 0) { ok = prove_plain_ungapped<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i]); decided = ok; }
-                            else if (round == 1) { ok = prove_plain_band<REV, IPX_PROVE_BAND_NARROW>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab); decided = ok; }
-                            else ok = prove_plain_band<REV, IPX_PROVE_BAND>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab);
-                        }
-                        if (!decided) open = true;
-                        else {
-                            if (!REV) r.mode = ok ? (rev_needed(b, r.score1) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE) : (b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT_P : IPX_MODE_NEED_BYTE_LOW_CMP);
-                            else {
-                                r.mode = IPX_MODE_BYTE;                      // certified: final; otherwise the stepped reverse pass decides
-                                if (!ok) { r.ref_begin1 = -1; r.read_begin1 = -1; }
-                            }
-                            b.res[i] = r;
-                            key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
-                        }
-                    }
+    uint32_t na = 0, nw = 0;                                       // queued jobs (the same in every lane); both queues carry over
+                                                                   // from chunk to chunk of the wave's walk (see k_prove_overflow)
+    // stage 0: the job's own lane, ungapped test; stage 1: narrow band; stage 2: wide band (its verdict stands).  i < 0: no job.
+    auto step = [&](int64_t i, int stage) {
+        int key = -1;
+        bool open = false;
+        if (i >= 0) {
+            IpxResult r = b.res[i];
+            const bool mine = REV ? r.mode == IPX_MODE_NEED_REV_PROOF : (r.mode == IPX_MODE_NEED_FWD_PROOF || r.mode == IPX_MODE_NEED_FWD_PROOF2);
+            if (mine) {
+                const int rid = b.ref_id[i];
+                const int8_t *rd = b.reads + b.read_off[i];
+                const int8_t *rf = b.refs_packed + b.refp_off[rid];
+                const int Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+                IpxProveTarget t;
+                if (!REV) {
+                    t.Lp = Lr; t.ncols = b.ref_len[rid]; t.r1 = r.read_end1; t.c1 = r.ref_end1; t.v1 = r.score1;
+                    t.e2 = r.mode == IPX_MODE_NEED_FWD_PROOF2 ? r.ref_end2 : -1; t.s2 = r.score2;
+                } else {
+                    t.Lp = r.read_end1 + 1; t.ncols = r.ref_end1 + 1; t.r1 = r.read_end1 - r.read_begin1; t.c1 = r.ref_end1 - r.ref_begin1;
+                    t.v1 = r.score1; t.e2 = -1; t.s2 = 0;
                 }
-                plan_note(b, key);
-                if (round < 2) {
-                    const uint64_t om = xl_ballot(open);
-                    if (open) queue[qnext + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)(i - cbase);
-                    qnext += (uint32_t)__builtin_popcountll(om);
+                const bool sane = t.r1 >= 0 && t.r1 < t.Lp && t.c1 >= 0 && t.c1 < t.ncols;
+                bool ok = false, decided = true;
+                if (sane) {
+                    if (stage == 0) { ok = prove_plain_ungapped<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i]); decided = ok; }
+                    else if (stage == 1) { ok = prove_plain_band<REV, IPX_PROVE_BAND_NARROW>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab); decided = ok; }
+                    else ok = prove_plain_band<REV, IPX_PROVE_BAND>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab);
+                }
+                if (!decided) open = true;
+                else {
+                    if (!REV) r.mode = ok ? (rev_needed(b, r.score1) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE) : (b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT_P : IPX_MODE_NEED_BYTE_LOW_CMP);
+                    else {
+                        r.mode = IPX_MODE_BYTE;                      // certified: final; otherwise the stepped reverse pass decides
+                        if (!ok) { r.ref_begin1 = -1; r.read_begin1 = -1; }
+                    }
+                    b.res[i] = r;
+                    key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
                 }
             }
-            qn = qnext;
         }
-        IPX_SYNC();                                                // the queue is free for the next chunk
+        plan_note(b, key);
+        if (stage < 2) {                                           // still open: the next stage's queue
+            uint32_t *q = stage == 0 ? qa : qb;
+            uint32_t &n = stage == 0 ? na : nw;
+            const uint64_t om = xl_ballot(open);
+            if (open) q[n + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            n += (uint32_t)__builtin_popcountll(om);
+        }
+    };
+    auto band_round = [&](const uint32_t *q, uint32_t first, uint32_t cnt, int stage) {
+        IPX_SYNC();                                                // queue entries written
+        step((uint32_t)lane < cnt ? (int64_t)q[first + lane] : (int64_t)-1, stage);
+    };
+    auto drain = [&](bool all) {
+        while (na >= 64u || (all && na > 0u)) {
+            const uint32_t cnt = na < 64u ? na : 64u;
+            band_round(qa, na - cnt, cnt, 1);                      // (from the tail: nothing moves)
+            na -= cnt;
+            while (nw >= 64u) { band_round(qb, nw - 64u, 64u, 2); nw -= 64u; }
+        }
+        while (all && nw > 0u) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, 2); nw -= cnt; }
+    };
+    for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
+        const int64_t cbase = chunk * CB * 64;
+        for (int sb = 0; sb < CB; ++sb) {
+            const int64_t ii = cbase + (int64_t)sb * 64 + lane;
+            step(ii < b.n_jobs ? ii : (int64_t)-1, 0);
+        }
+        drain(false);
     }
+    drain(true);
 }
 
 // ------------------------------------------------------------------------------------------------
