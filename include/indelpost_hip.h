@@ -131,7 +131,12 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
  *  16 column maxima in global scratch instead of LDS
  *  32 16-bit passes (and the 8-bit bracket stages) in packed integers even where packed halves are exact
  *  64 half-precision passes column by column with lazy-F instead of as a wavefront over the SSE lanes
- * 128 8-bit lower-bound stage in the reference's 16-lane layout (8 reads per wave) instead of two lanes per GPU lane */
+ * 128 8-bit lower-bound stage in the reference's 16-lane layout (8 reads per wave) instead of two lanes per GPU lane
+ * 256 the r02 order of the 8-bit passes (lower bound, upper bound, stepped) instead of the plain recurrence first + proofs
+ * 512 one launch per read-length class (no rare class listed under the next populated one)
+ *1024 one launch per class instead of one per occupancy tier (wavefront kernels and the stepped 8-bit passes)
+ *2048 what a proof leaves open takes the lower-bound stage before the stepped pass
+ *4096 small batches too take the lane-per-job traceback kernels      8192 every CIGAR through banded_sw's DP (no ungapped shortcut) */
 int ipx_set_routing(ipx_ctx *c, int flags);
 
 /* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,
