@@ -2258,10 +2258,42 @@ IPX_DEV bool prove_plain_ungapped(const IpxBatch &b, const IpxProveTarget &t, co
     return t.e2 > cs && u - go - (t.e2 - cs - 1) * ge >= t.s2;
 }
 
+// (wide band, forward) TAIL THEN DESCENT.  The second-best column -- the first one right of the mask -- usually holds the tail of the best
+// alignment, a horizontal gap from one of its last cells, and the largest value in that column is the one whose tail ran along one of the
+// read's LAST rows and then came DOWN the diagonal through the rows below: the letters the alignment left unaligned, which out there
+// may match by chance, and the padding rows, which cost nothing (emulator, 3 000 reads of config 2a: every proof the band left open
+// was such a column, 1-2 points above the band's own witnesses; this one closes two thirds of them).  wrow[q * 64] (LDS, this lane's
+// column): best hm + c * gapE over the band cells, at least IPX_PROVE_EXT_COLS columns left of e2, of read row Lp - IPX_PROVE_EXT + q.
+// Tail along row r0 up to column cs, then down the diagonal to (R, e2): every step is a safe move -- the horizontal gap is fed by the
+// main loop's H of the band cell, each diagonal step reads the final H of the column before -- so the sum is a lower bound of the
+// reference's H at (R, e2).  A call (rare: only where the band's witnesses fall short), so its registers are not the band loop's.
+#define IPX_PROVE_EXT 8
+#define IPX_PROVE_EXT_COLS 24
+IPX_NOINLINE_DEV int prove_plain_tail_descent(const IpxProveTarget &t, const int8_t *rd, const int8_t *rf, int go, int ge, const uint64_t *coltab,
+                                              const int *wrow, int rows)
+{
+    int best = -1;
+    for (int q = 0; q < IPX_PROVE_EXT; ++q) {
+        const int r0 = t.Lp - IPX_PROVE_EXT + q, w = wrow[q * 64];
+        if (r0 < 0 || w < 0) continue;
+        for (int R = r0 + 1; R < rows; ++R) {
+            const int cs = t.e2 - (R - r0);
+            const int real = (R < t.Lp ? R : t.Lp - 1) - r0;                         // rows of the descent that carry read letters
+            int v = w - go - (cs - 1) * ge;
+            for (int k = 1; k <= real; ++k)
+                v += (int)(int8_t)(coltab[prove_read_letter<false>(rd, t.Lp, r0 + k)] >> (8 * prove_ref_letter<false>(rf, t.ncols, cs + k)));
+            if (v > best) best = v;
+        }
+    }
+    return best;
+}
+
 template <bool REV, int BW>
-IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const int8_t *rd, const int8_t *rf, int go, int ge, const uint64_t *coltab)
+IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const int8_t *rd, const int8_t *rf, int go, int ge, const uint64_t *coltab,
+                              int *wrow = nullptr)
 {
     constexpr int HB = BW / 2;
+    constexpr bool EXTW = !REV && BW == IPX_PROVE_BAND;
     const int S8 = (t.Lp + 15) >> 4;                       // segLen of the 8-bit pass (ssw.c:221)
     const int rows = 16 * S8;
     const int d0 = t.c1 - t.r1;
@@ -2279,7 +2311,7 @@ IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const 
         a_next = rr + 1 < t.Lp ? prove_read_letter<REV>(rd, t.Lp, rr + 1) : 4;
         const uint64_t row = rr < t.Lp ? coltab[a] : 0ull;  // padding rows score 0 against every letter
         const bool cross = seg == 0;
-        int e = 0, hleft = 0;
+        int e = 0, hleft = 0, rowbest = -(1 << 28);
         IPX_UNROLL
         for (int k = 0; k < BW; ++k) {
             const unsigned cl = (unsigned)(win >> (4 * k)) & 7u;
@@ -2305,8 +2337,10 @@ IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const 
             if (t.e2 >= 0 && cl <= 4u) {
                 if (c == t.e2 && hf > w2) w2 = hf;
                 if (c < t.e2 && hm + c * ge > wb) wb = hm + c * ge;
+                if (EXTW && c < t.e2 - IPX_PROVE_EXT_COLS && hm + c * ge > rowbest) rowbest = hm + c * ge;
             }
         }
+        if (EXTW && wrow && rr >= t.Lp - IPX_PROVE_EXT && rr < t.Lp) wrow[(rr - (t.Lp - IPX_PROVE_EXT)) * 64] = rowbest;   // (see prove_plain_tail_descent)
         if (rr == t.r1) got = Hf[HB];
         win = (win >> 4) | ((uint64_t)prove_ref_letter<REV>(rf, t.ncols, rr + 1 + d0 + HB) << (4 * (BW - 1)));
         if (++seg == S8) seg = 0;
@@ -2314,6 +2348,10 @@ IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const 
     if (got < t.v1) return false;
     if (t.e2 < 0) return true;
     if (wb - go - (t.e2 - 1) * ge > w2) w2 = wb - go - (t.e2 - 1) * ge;
+    if (EXTW && wrow && w2 < t.s2 && rows - (t.Lp - IPX_PROVE_EXT) <= IPX_PROVE_EXT_COLS) {
+        const int v = prove_plain_tail_descent(t, rd, rf, go, ge, coltab, wrow, rows);
+        if (v > w2) w2 = v;
+    }
     return w2 >= t.s2;
 }
 
@@ -2324,6 +2362,7 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
     uint32_t *qa = (uint32_t *)(IPX_LDS_BASE + 64);                // jobs waiting for the narrow band
     uint32_t *qb = qa + IPX_PROVE_QA;                              // jobs waiting for the wide band
+    int *wrow = (int *)(qb + IPX_PROVE_QB) + lane;                 // [IPX_PROVE_EXT][64]: prove_plain_tail_descent
     if (lane < 5) {
         uint64_t tt = 0;
         for (int c = 0; c < 5; ++c) tt |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
@@ -2360,7 +2399,10 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
                 if (sane) {
                     if (stage == 0) { ok = prove_plain_ungapped<REV>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i]); decided = ok; }
                     else if (stage == 1) { ok = prove_plain_band<REV, IPX_PROVE_BAND_NARROW>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab); decided = ok; }
-                    else ok = prove_plain_band<REV, IPX_PROVE_BAND>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab);
+                    else {
+                        if (!REV) { IPX_UNROLL for (int q = 0; q < IPX_PROVE_EXT; ++q) wrow[q * 64] = -1; }   // (rows the read does not have)
+                        ok = prove_plain_band<REV, IPX_PROVE_BAND>(b, t, rd, rf, b.gap_open[i], b.gap_ext[i], coltab, REV ? nullptr : wrow);
+                    }
                 }
                 if (!decided) open = true;
                 else {

@@ -383,7 +383,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // start in the stepped pass: next_pass_key.)
             if (d.any_low) {
                 ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing);
-                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(0), b, prove_chunk);
+                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
                 if (!b.exact_direct) {
                     ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
                     ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], ws, d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1, 0, low2 ? 16 : 8);
@@ -427,7 +427,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, 16);
                 ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing);
-                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(0), b, prove_chunk);
+                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
             }
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
             ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], ws, has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing, 3, 0, 8);
