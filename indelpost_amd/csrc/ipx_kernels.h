@@ -712,26 +712,14 @@ IPX_DEV void dp_pass_body(const IpxBatch &b, const IpxPlan &p, int cls_lo, int c
         }
 
         // Columns go in groups of four = one dword of window letters.  All global-memory traffic of the
-        // column loop sits at the top of a group: the dword fetched one group ahead is consumed, the next
-        // one is requested and the previous group's four column maxima are stored -- so the only wait on
+        // column loop sits at the edges of a group: at its top the previous group's four column maxima are stored, at its
+        // end the dword fetched one group ahead is consumed and the next one requested -- so the only wait on
         // global memory is for operations issued a whole group (thousands of cycles) earlier.
         bool stop = false;
         int tdone = -1;                                             // last column processed
         pk16 cm4 = 0;                                               // lane l<4: maximum of column (group base + l)
         for (int t0 = 0; t0 < T && !stop; t0 += 4) {
-          if (t0 > 0) {
-              IPX_UNROLL
-              for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
-              IPX_VMEM_FENCE();
-              IPX_UNROLL
-              for (int h = 0; h < 2; ++h) {
-                  int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 1) : (t0 >> 2) + 1;
-                  if (k < 0) k = 0;
-                  if (k > kmax[h]) k = kmax[h];
-                  nxt[h] = load_global_u32(refw[h] + k);
-              }
-              if (!REV && l < 4) { if (mc_lds) maxcol[(t0 - 4 + l) * G + g] = cm4; else store_global_u32(maxcol + ((t0 - 4 + l) * G + g), cm4); }
-          }
+          if (t0 > 0 && !REV && l < 4) { if (mc_lds) maxcol[(t0 - 4 + l) * G + g] = cm4; else store_global_u32(maxcol + ((t0 - 4 + l) * G + g), cm4); }
           const int tn = t0 + 4 < T ? t0 + 4 : T;
           IPX_NOUNROLL
           for (int t = t0; t < tn; ++t) {
@@ -1131,6 +1119,19 @@ IPX_DEV void dp_pass_body(const IpxBatch &b, const IpxPlan &p, int cls_lo, int c
             for (int h = 0; h < 2; ++h)
                 alive = alive || ((t + 1 < tb[h] + ncol[h]) && ((done >> (16 * h)) & 0xFFFFu) == 0);
             if (!xl_any(alive)) { stop = true; break; }
+          }
+          // the next group's letters have arrived (requested a group ago); request those of the group after it -- at the END of the
+          // body and unconditionally (see dp_skew_tile: requested at the top under "not the first group", every group waited for the
+          // request it had just issued)
+          IPX_UNROLL
+          for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
+          IPX_VMEM_FENCE();
+          IPX_UNROLL
+          for (int h = 0; h < 2; ++h) {
+              int k = REV ? (idx0[h] >> 2) - ((t0 >> 2) + 2) : (t0 >> 2) + 2;
+              if (k < 0) k = 0;
+              if (k > kmax[h]) k = kmax[h];
+              nxt[h] = load_global_u32(refw[h] + k);
           }
         }
         if (!REV && tdone >= 0 && l <= (tdone & 3)) {                                                             // last group
