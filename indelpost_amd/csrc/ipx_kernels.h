@@ -1285,7 +1285,7 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
 // columns, a hundred-odd dependent instructions each), one after the other on the stream.  Here block b takes the b-th tile of
 // the concatenated tile lists of the launch's classes (grid = the number of tiles the previous run of the context saw), so the
 // tiles of all classes are in flight together and the launch lasts as long as its longest tile.
-#define IPX_PASS_TIER_LO 1                      // classes the launch covers (8-bit segLen: reads of up to 256 bp)
+#define IPX_PASS_TIER_LO 0                      // classes the launch covers (8-bit segLen: reads of up to 256 bp; 0 = empty reads)
 #define IPX_PASS_TIER_HI 16
 template <int W, int S, bool REV, int STAGE>
 IPX_NOINLINE_DEV void dp_pass_body_call(const IpxBatch &b, const IpxPlan &p, int maxcols, int pass, uint32_t rank, uint32_t nrank)

@@ -211,8 +211,10 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
         if constexpr (W == 16 && STAGE == IPX_STAGE_EXACT) {
             if (half == 0 && ipx_perm_profile_ok(b.mat, routing) && !(routing & IPX_ROUTE_NO_TIERS)) {
                 int n = 0;
+                // (reverse pass: EVERY class up to the longest read's -- the class of the aligned prefix is decided on the device, the bodies
+                //  are all there, and no sweep launch is left for the classes below)
                 for (int c = from > IPX_PASS_TIER_LO ? from : IPX_PASS_TIER_LO; c <= top && c <= IPX_PASS_TIER_HI; ++c)
-                    if (REV ? (hs[c] || (c + 1 <= top && hs[c + 1])) : hs[c] != 0) { tier |= 1u << c; ++n; }
+                    if (REV || hs[c] != 0) { tier |= 1u << c; ++n; }
                 if (n < 2) tier = 0;
             }
             if (tier) {
@@ -225,7 +227,7 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
         }
         for (int c = from; c <= top && c <= IPX_MAX_EXACT; ++c) {
             const bool own = REV ? (hs[c] || (c + 1 <= top && hs[c + 1])) : hs[c] != 0;
-            if (own && ((tier >> (c < 32 ? c : 31)) & 1u) && c < 32) { exact[half] |= 1ull << c; continue; }
+            if (c < 32 && ((tier >> c) & 1u)) { exact[half] |= 1ull << c; continue; }
             if (own) { exact[half] |= 1ull << c; ipx_launch_dp_class<BE, W, REV, STAGE>(be, b, p, c + half * IPX_SLOW_BASE, maxcols, kclass, pass, routing); }
         }
         for (int c = from; c <= top && c < IPX_MAX_SEG; ++c)
