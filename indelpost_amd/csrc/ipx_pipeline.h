@@ -370,13 +370,21 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     // the fast-gap classes of a 16-bit pass: from the planned set as wavefronts, or class by class (ipx_launch_dp); slow-gap classes always the latter
     const int word_from = d.word_sets ? d.word_from : 0;         // fast-gap 16-bit classes below this: wavefront launches from the planned sets
     const int prove_chunk = b.n_jobs >= IPX_PROVE_CHUNK_MIN_JOBS ? IPX_PROVE_CHUNK : 1;   // (small batches: shortest chain of rounds per wave)
+    // grids of the proof kernels (a block = a wave walking chunks of 64 * prove_chunk jobs): the overflow proof one chunk per wave; the plain
+    // proofs -- nearly every read takes a band there -- TWO once there are many, so that the band queues carry over and the rounds run on full
+    // waves (measured on 2a, 250 k jobs per stream: one chunk per wave 73.2 M aln/s, two 75.1, four 68.9: fewer waves than that leave the
+    // launch to its own latency)
+    const int64_t prove_nchunk = (b.n_jobs + 64 * prove_chunk - 1) / (64 * prove_chunk);
+    const int prove_cap = be.flat_grid((int64_t)1 << 40);         // (the backend's cap on such grids)
+    const int prove_grid1 = (int)(prove_nchunk < prove_cap ? (prove_nchunk > 0 ? prove_nchunk : 1) : prove_cap);
+    const int prove_grid2 = prove_nchunk >= 512 ? (prove_grid1 + 1) / 2 : prove_grid1;
     if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
         if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], ws, d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, 3, word_from, 16);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
-        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(cap), b, cap, prove_chunk);
+        be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, prove_grid1, 64, ipx_prove_lds_bytes(cap), b, cap, prove_chunk);
     }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)
         if (d.plain_first) {
@@ -385,7 +393,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // start in the stepped pass: next_pass_key.)
             if (d.any_low) {
                 ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing);
-                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
+                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
                 if (!b.exact_direct) {
                     ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
                     ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], ws, d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1, 0, low2 ? 16 : 8);
@@ -429,7 +437,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, 16);
                 ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing);
-                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, be.flat_grid(b.n_jobs * 4), 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
+                be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
             }
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
             ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], ws, has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing, 3, 0, 8);
