@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 D=gpurun_out/${1:-prof}
 WL=${2:-"2b 2a 4"}
 mkdir -p $D
-python3 bench.py --steps 10 --warmup 2 > $D/bench.log 2> $D/bench.err; echo "bench rc=$?"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $D/bench.log 2> $D/bench.err; echo "bench rc=$?"
 for w in $WL; do
   B="python3 bench.py --workload $w --no-subconfigs --no-cpu-baseline --no-single-stream"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/$w/kt -- $B --steps 5 --warmup 2 > $D/$w.kt.log 2> $D/$w.kt.err; echo "$w kt rc=$?"
