@@ -1512,13 +1512,21 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
         }
         // the four steps of the group, unrolled: which pair and which bytes of it a step takes are compile-time, and the
         // hand-over registers (Hl_old / Hl_cur) rotate by renaming
+        // The score-table words of a step are looked up ONE STEP AHEAD (inside a group): the letters move down the lanes independently of
+        // the DP, so the two LDS reads of step u + 1 are issued before the stripe of step u and have arrived when it is done.
+        // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
+        // (one v_perm_b32 with a per-lane selector: the first lane picks its two bytes of the pair, the others the lane above's letters)
+        let = pk_perm(xl_row_shr1(let), pairA, lsel0);
+        uint32_t tabn0 = *(const uint32_t *)(lds + (let & 0xFFu)), tabn1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
         IPX_UNROLL
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u;
-            // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
-            // (one v_perm_b32 with a per-lane selector: the first lane picks its two bytes of the pair, the others the lane above's letters)
-            let = pk_perm(xl_row_shr1(let), (u & 2) ? pairB : pairA, (u & 1) ? lsel1 : lsel0);
-            const uint32_t tab0 = *(const uint32_t *)(lds + (let & 0xFFu)), tab1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
+            const uint32_t tab0 = tabn0, tab1 = tabn1;
+            if (u < 3) {
+                let = pk_perm(xl_row_shr1(let), ((u + 1) & 2) ? pairB : pairA, ((u + 1) & 1) ? lsel1 : lsel0);
+                tabn0 = *(const uint32_t *)(lds + (let & 0xFFu));
+                tabn1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
+            }
             // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
             const pk16 vH = xl_row_shr1(Hl_old) & nz;
             pk16 vF = xl_row_shr1(vFend) & nz;
