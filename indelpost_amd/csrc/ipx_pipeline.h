@@ -452,7 +452,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // a fifth of the time one lane needs for it (r03, 1000 jobs: 0.76 -> 0.42 ms of traceback), and the lane-per-job launch is skipped
             const int tb_all_general = !(routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) && b.n_jobs <= 2048;
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 64, b, ws.tb_list, ws.tb_list_n, ws.tb_esc, tb_all_general,
-                      (routing & IPX_ROUTE_TB_NO_UNGAPPED) ? 0 : 1);
+                      ((routing & IPX_ROUTE_TB_NO_UNGAPPED) || tb_all_general) ? 0 : 1);   // (a small batch has a wave for every job: the check would only add its own latency)
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
             const int want = d.max_read_len > 0 ? d.max_read_len : 1;
             const int rowcap = want < IPX_TBF_ROWCAP ? want : IPX_TBF_ROWCAP;
