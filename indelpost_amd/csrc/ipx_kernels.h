@@ -2172,6 +2172,7 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
             na -= cnt;
             while (nw >= 64u) { band_round(qb, nw - 64u, 64u, true); nw -= 64u; }
         }
+        while (nw >= 64u) { band_round(qb, nw - 64u, 64u, true); nw -= 64u; }
         while (all && nw > 0u) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, true); nw -= cnt; }
     };
     for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
@@ -2201,8 +2202,14 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
             }
             plan_note(b, key);
             const uint64_t om = xl_ballot(open);
-            if (open) qa[na + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
-            na += (uint32_t)__builtin_popcountll(om);
+            // (a small batch -- one block of 64 jobs per chunk -- takes the wide band at once: two rounds in a row would only add latency)
+            if (CB == 1) {
+                if (open) qb[nw + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                nw += (uint32_t)__builtin_popcountll(om);
+            } else {
+                if (open) qa[na + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                na += (uint32_t)__builtin_popcountll(om);
+            }
         }
         drain(false);
     }
@@ -2426,9 +2433,10 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
             }
         }
         plan_note(b, key);
-        if (stage < 2) {                                           // still open: the next stage's queue
-            uint32_t *q = stage == 0 ? qa : qb;
-            uint32_t &n = stage == 0 ? na : nw;
+        if (stage < 2) {                                           // still open: the next stage's queue (a small batch -- one block of 64
+            const bool to_a = stage == 0 && CB > 1;                //  jobs per chunk -- goes from the ungapped test to the wide band at once)
+            uint32_t *q = to_a ? qa : qb;
+            uint32_t &n = to_a ? na : nw;
             const uint64_t om = xl_ballot(open);
             if (open) q[n + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
             n += (uint32_t)__builtin_popcountll(om);
@@ -2445,6 +2453,7 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
             na -= cnt;
             while (nw >= 64u) { band_round(qb, nw - 64u, 64u, 2); nw -= 64u; }
         }
+        while (nw >= 64u) { band_round(qb, nw - 64u, 64u, 2); nw -= 64u; }
         while (all && nw > 0u) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, 2); nw -= cnt; }
     };
     for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
