@@ -2820,7 +2820,9 @@ struct IpxTbScratch {
 // (2 * max(aligned window span, aligned read span) + 8 entries: long reads, long deletions) keeps them in its block's region of the
 // global scratch instead (r03: windows up to 32 000 bp, reads up to 4 096 bp).
 // ------------------------------------------------------------------------------------------------
-static inline int ipx_tbc_lds_bytes(int arrcap) { return 64 + 512 + 16 * arrcap; }
+#define IPX_TBC_STAGE 1024        // letters of a job's read / window rectangle staged in LDS when each has at most this many (r03)
+#define IPX_TBC_DIR_LDS 8192      // direction bytes of a job kept in LDS while there are at most this many (the walk back is a chain of dependent reads)
+static inline int ipx_tbc_lds_bytes(int arrcap) { return 64 + 512 + 2 * IPX_TBC_STAGE + 16 * arrcap + IPX_TBC_DIR_LDS; }
 
 IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t *list_n, uint8_t *dir_scratch,
                                int64_t dircap, int arrcap_g, uint32_t *cig_scratch, int cigcap, int32_t *band_scratch, int arrcap_lds)
@@ -2830,7 +2832,12 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
     int8_t *matl = (int8_t *)lds;
     int32_t *lastH = (int32_t *)(lds + 64);
     int32_t *lastF = lastH + 64;
-    uint8_t *dir = dir_scratch + (int64_t)IPX_BID * dircap;
+    // this job's letters, staged once: a row then reads LDS where it read HBM -- with one cell per lane and three barriers per row, a
+    // row WAS the latency of its global loads (r03: a typical job 0.15 -> 0.06 ms, and every doubling of the band costs that again)
+    int8_t *sread = (int8_t *)(lastF + 64), *sref = sread + IPX_TBC_STAGE;
+    int32_t *band_lds = (int32_t *)(sref + IPX_TBC_STAGE);
+    uint8_t *dir_lds = (uint8_t *)(band_lds + 4 * arrcap_lds);
+    uint8_t *dir_glob = dir_scratch + (int64_t)IPX_BID * dircap;
     uint32_t *cig = cig_scratch + (int64_t)IPX_BID * cigcap;
     if (lane < 25) matl[lane] = b.mat[lane];
     IPX_SYNC();
@@ -2858,18 +2865,29 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
         const int need = 2 * (len > 0 ? len : 1) + 8;
         const bool in_lds = need <= arrcap_lds;
         const int arrcap = in_lds ? arrcap_lds : arrcap_g;
-        int32_t *hb = in_lds ? lastF + 64 : band_scratch + (size_t)IPX_BID * 4u * (size_t)arrcap_g;
+        int32_t *hb = in_lds ? band_lds : band_scratch + (size_t)IPX_BID * 4u * (size_t)arrcap_g;
         int32_t *eb = hb + arrcap;
         int32_t *hc = eb + arrcap;
         int32_t *en = hc + arrcap;
         for (int q = lane; q < (need < arrcap ? need : arrcap); q += 64) { hb[q] = 0; eb[q] = 0; hc[q] = 0; en[q] = 0; }
+        const bool staged = readLen <= IPX_TBC_STAGE && refLen <= IPX_TBC_STAGE;
+        if (staged) {
+            for (int q = lane; q < readLen; q += 64) { const int a = readp[q]; sread[q] = (int8_t)((unsigned)a > 4u ? 4 : a); }
+            for (int q = lane; q < refLen; q += 64) { const int ri = rb + q; sref[q] = (ri >= 0 && ri < fullRef) ? refp[ri] : (int8_t)0; }
+        }
         IPX_SYNC();
 
+        uint8_t *dir = dir_lds;                                   // (moves to the global scratch when a doubled band outgrows the LDS region)
         do {
             width = bw * 2 + 3;
             width_d = bw * 2 + 1;
             const int64_t cells = (int64_t)width_d * (readLen > 0 ? readLen : 1);
             if (width + 1 > arrcap || cells > dircap) { broken = true; break; }
+            if (dir == dir_lds && cells > IPX_TBC_DIR_LDS) {       // what the narrower iterations left behind goes along (ssw.c:610: one buffer)
+                for (int q = lane; q < extent; q += 64) dir_glob[q] = dir_lds[q];
+                dir = dir_glob;
+                IPX_SYNC();
+            }
             for (int64_t q = extent + lane; q < cells; q += 64) dir[q] = 0;
             if ((int)cells > extent) extent = (int)cells;
             for (int j = 1 + lane; j < width - 1; j += 64) hb[j] = 0;                       // ssw.c:627
@@ -2883,7 +2901,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
                 const int xp = i - 1 - bw > 0 ? i - 1 - bw : 0;                            // ... of row i-1
                 if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }   // ssw.c:633
                 IPX_SYNC();
-                int rc = readp[i];
+                int rc = staged ? (int)sread[i] : (int)readp[i];
                 if ((unsigned)rc > 4u) rc = 4;
                 const int ncell = end - beg + 1;
                 const int cp = (ncell + 63) / 64;                                          // cells per lane
@@ -2897,7 +2915,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
                     const int t2 = i == 0 ? -gapE : eb[e] - gapE;
                     const int ev = t1 > t2 ? t1 : t2;
                     const int ri = rb + j;
-                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    const int rcode = staged ? (int)sref[j] : ((ri >= 0 && ri < fullRef) ? refp[ri] : 0);
                     int a = hb[e - 1] + matl[rcode * 5 + rc];
                     if (ev > a) a = ev;
                     if (a < 0) a = 0;                                                      // A_j
@@ -2952,7 +2970,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
                     const int f1 = fcur > 0 ? fcur : 0;
                     const int tt1 = e1 > f1 ? e1 : f1;
                     const int ri = rb + j;
-                    const int rcode = (ri >= 0 && ri < fullRef) ? refp[ri] : 0;
+                    const int rcode = staged ? (int)sref[j] : ((ri >= 0 && ri < fullRef) ? refp[ri] : 0);
                     const int tt2 = hb[e - 1] + matl[rcode * 5 + rc];
                     const int hv = tt1 > tt2 ? tt1 : tt2;
                     const int dh = tt1 <= tt2 ? 0 : (e1 > f1 ? 1 : 2);

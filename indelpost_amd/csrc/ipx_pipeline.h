@@ -659,7 +659,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
 }
 
 // scratch sizing shared by both back-ends -------------------------------------------------------
-#define IPX_TBC_ARRCAP_LDS 2048     // band rows of up to this many entries stay in LDS (33 KB per one-wave block)
+#define IPX_TBC_ARRCAP_LDS 1024     // band rows of up to this many entries stay in LDS (16 KB per one-wave block; with the staged letters and the direction bytes 27 KB: five blocks per CU)
 struct IpxTbSizing { int arrcap, dircap, cigcap, arrcap_lds; };
 static inline IpxTbSizing ipx_tb1_sizing(const IpxDims &d)
 {
