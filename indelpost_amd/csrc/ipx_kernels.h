@@ -2166,14 +2166,11 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
     };
     // run the rounds that are full (all = false) or everything that waits (all = true: the wave's last chunk is done)
     auto drain = [&](bool all) {
-        while (na >= 64u || (all && na > 0u)) {
-            const uint32_t cnt = na < 64u ? na : 64u;
-            band_round(qa, na - cnt, cnt, false);                  // (from the tail: nothing moves)
-            na -= cnt;
-            while (nw >= 64u) { band_round(qb, nw - 64u, 64u, true); nw -= 64u; }
+        for (;;) {                                                 // (one call site per band, see k_prove_plain)
+            if (nw >= 64u || (all && na == 0u && nw > 0u)) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, true); nw -= cnt; continue; }
+            if (na >= 64u || (all && na > 0u)) { const uint32_t cnt = na < 64u ? na : 64u; band_round(qa, na - cnt, cnt, false); na -= cnt; continue; }
+            break;
         }
-        while (nw >= 64u) { band_round(qb, nw - 64u, 64u, true); nw -= 64u; }
-        while (all && nw > 0u) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, true); nw -= cnt; }
     };
     for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
         const int64_t cbase = chunk * CB * 64;
@@ -2434,27 +2431,25 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
         }
         plan_note(b, key);
         if (stage < 2) {                                           // still open: the next stage's queue (a small batch -- one block of 64
-            const bool to_a = stage == 0 && CB > 1;                //  jobs per chunk -- goes from the ungapped test to the wide band at once)
-            uint32_t *q = to_a ? qa : qb;
-            uint32_t &n = to_a ? na : nw;
-            const uint64_t om = xl_ballot(open);
-            if (open) q[n + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)i;
-            n += (uint32_t)__builtin_popcountll(om);
+            const uint64_t om = xl_ballot(open);                   //  jobs per chunk -- goes from the ungapped test to the wide band at once)
+            const uint32_t at = (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull)), cnt = (uint32_t)__builtin_popcountll(om);
+            if (stage == 0 && CB > 1) { if (open) qa[na + at] = (uint32_t)i; na += cnt; }
+            else { if (open) qb[nw + at] = (uint32_t)i; nw += cnt; }
         }
     };
     auto band_round = [&](const uint32_t *q, uint32_t first, uint32_t cnt, int stage) {
         IPX_SYNC();                                                // queue entries written
         step((uint32_t)lane < cnt ? (int64_t)q[first + lane] : (int64_t)-1, stage);
     };
+    // full rounds first (the wide band's before the narrow band's, whose leftovers feed it); with `all` -- the wave's last chunk is done --
+    // the remainders too: the narrow queue's, then the wide queue's.  (ONE call site per band: inlined three times, the wide band's code
+    // took the kernel from 164 to 248 registers.)
     auto drain = [&](bool all) {
-        while (na >= 64u || (all && na > 0u)) {
-            const uint32_t cnt = na < 64u ? na : 64u;
-            band_round(qa, na - cnt, cnt, 1);                      // (from the tail: nothing moves)
-            na -= cnt;
-            while (nw >= 64u) { band_round(qb, nw - 64u, 64u, 2); nw -= 64u; }
+        for (;;) {
+            if (nw >= 64u || (all && na == 0u && nw > 0u)) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, 2); nw -= cnt; continue; }
+            if (na >= 64u || (all && na > 0u)) { const uint32_t cnt = na < 64u ? na : 64u; band_round(qa, na - cnt, cnt, 1); na -= cnt; continue; }
+            break;
         }
-        while (nw >= 64u) { band_round(qb, nw - 64u, 64u, 2); nw -= 64u; }
-        while (all && nw > 0u) { const uint32_t cnt = nw < 64u ? nw : 64u; band_round(qb, nw - cnt, cnt, 2); nw -= cnt; }
     };
     for (int64_t chunk = IPX_BID; chunk < nchunk; chunk += IPX_GDIM) {
         const int64_t cbase = chunk * CB * 64;
