@@ -1,0 +1,49 @@
+"""Register budgets of the kernels whose occupancy the measured numbers rest on, read from the built code objects (no GPU needed).
+A kernel that crosses a waves-per-SIMD step (128 / 168 registers) or starts to spill loses 10-20 % without any test failing --
+r03 saw it twice (k_prove_plain 164 -> 248 registers: 2a 75 -> 61.5 M aln/s); this is the tripwire."""
+import glob
+import os
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+BUDGET = {  # kernel name prefix: (max registers, max spilled registers)
+    "k_dp_skew<19, false, 0>": (168, 0),        # headline forward pass: three waves per SIMD
+    "k_dp_skew<19, true, 0>": (168, 0),
+    "k_dp_skew<13, false, 0>": (128, 0),        # four waves
+    "k_dp_skew<20, false, 2>": (168, 0),        # plain 8-bit recurrence of 150 bp reads
+    "k_dp_skew<25, false, 0>": (168, 40),       # three waves at the price of a few spills
+    "k_dp_skew<32, false, 0>": (256, 0),
+    "k_dp_skew_tier<13, 19, false, 0>": (168, 8),
+    "k_dp_skew_tier<13, 19, true, 0>": (168, 8),
+    "k_prove_plain<false>": (168, 0),
+    "k_prove_plain<true>": (128, 0),
+    "k_prove_overflow": (128, 0),
+    "k_tb_coop": (128, 0),
+    "k_tb_fast<2>": (128, 0),
+}
+
+
+def test_register_budgets_of_the_hot_kernels():
+    import kernel_regs
+    objs = sorted(glob.glob(os.path.join(ROOT, "indelpost_amd", "csrc", "build", "*.o")))
+    if not objs or not os.path.exists(kernel_regs.LLVM + "clang-offload-bundler"):
+        pytest.skip("no built objects / no ROCm tools here")
+    import subprocess
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            rows += kernel_regs.kernels_of(o, tmp)
+    names = subprocess.run(["c++filt"], input="\n".join(r.get(".name", "?") for r in rows), capture_output=True, text=True).stdout.split("\n")
+    seen = {}
+    for r, n in zip(rows, names):
+        n = n.replace("void ", "").split("(")[0]
+        seen[n] = (int(r.get(".vgpr_count", 0)), int(r.get(".vgpr_spill_count", 0)))
+    for k, (vmax, smax) in BUDGET.items():
+        assert k in seen, "kernel %s not found in the built objects" % k
+        v, sp = seen[k]
+        assert v <= vmax and sp <= smax, "%s: %d registers, %d spilled (budget %d / %d)" % (k, v, sp, vmax, smax)
