@@ -684,7 +684,7 @@ def is_junctional(read):
     return read["is_covering"] if read["intron_pattern"] == (0, 0) else True
 
 
-def check_overhangs(pileup, splice_rate=0.1):
+def check_overhangs(pileup, splice_rate=0.2):
     """(intron, overhanging reads) when the locus sits at a well-supported exon boundary (pileup.pyx:427-451)"""
     from .retarget import most_common
     intron_ptrns = [r["intron_pattern"] for r in pileup if is_junctional(r)]

@@ -91,3 +91,21 @@ def test_many_loci_share_one_batch_per_level(cases, port_as_gpu):
         got = [{"read_name": r["read_name"], "is_target": r.get("is_target"), "undetermined": r.get("undetermined", False),
                 "mismatches#": DR.dig(r["mismatches"])} for r in res]
         assert got == sc["realn"]
+
+
+def test_check_overhangs_default_splice_rate_matches_the_reference():
+    """pileup.pyx:435: the default threshold is 0.2 and the only caller passes none (varaln.pyx:260) -- loci whose dominant intron is
+    supported by 10-20 % of the junctional reads must answer None.  Vectors: oracle/gen_overhang_rate_golden.py (reference text)."""
+    import json
+    import os
+    from indelpost_amd import pileup as P
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "overhang_rate_cases.json")))["cases"]
+    between = 0
+    for c in cases:
+        pl = [{"intron_pattern": tuple(r[0]), "is_covering": r[1], "covering_subread": tuple(r[2]) if r[2] else None, "aln_start": r[3], "aln_end": r[4]}
+              for r in c["pileup"]]
+        ans = P.check_overhangs(pl)
+        got = None if ans is None else {"intron": list(ans[0]), "overhangs": [i for i, r in enumerate(pl) if any(r is o for o in ans[1])]}
+        assert got == c["expected"], (c["support"], got, c["expected"])
+        between += 0.1 <= c["support"] < 0.2
+    assert between >= 20
