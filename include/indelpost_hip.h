@@ -108,8 +108,8 @@ enum {
     IPX_OK = 0,
     IPX_ERR_NO_DEVICE = -1,     /* no usable GPU / HIP runtime error: see ipx_last_error() */
     IPX_ERR_ARG = -2,
-    IPX_ERR_READ_TOO_LONG = -3, /* a read needs segLen > 64 (reads > 512 bp in the 16-bit pass) */
-    IPX_ERR_REF_TOO_LONG = -4,  /* a window is longer than 4096 */
+    IPX_ERR_READ_TOO_LONG = -3, /* a read is longer than 4 096 bp (IPX_LONG_MAX_READ) */
+    IPX_ERR_REF_TOO_LONG = -4,  /* a window is longer than 32 000 bp (IPX_MAX_REFLEN) */
     IPX_ERR_CIGAR_POOL = -5,    /* caller's cigar pool too small */
     IPX_ERR_INTERNAL = -6
 };
@@ -185,6 +185,10 @@ int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int
 /* host-side helper: FNV-1a (32 bit) of every job's BAM-encoded CIGAR ops, 2166136261 for a job without CIGAR (whole batches are
  * compared op for op with the reference through these, and record digests are built on them) */
 void ipx_cigar_hashes(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, uint32_t *out);
+/* host-side helper: 64-bit digest (XXH64, seed 0) of a batch's results in job order -- per job ten little-endian int64: score1, score2,
+ * ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, flag, cigar_len, cigar_hash[i] (from ipx_cigar_hashes).  bench.py compares it
+ * with the digest of the reference's results on the same job table (tests/golden/bench_digests.json). */
+uint64_t ipx_record_digest(const ipx_result *rec, const uint32_t *cigar_hash, int64_t n);
 
 /* deterministic synthetic workload of SURVEY.md section 8d (xorshift64), host side:
  * one window of `wl` codes and n reads of `rl` codes; returns the final generator state */

@@ -2421,7 +2421,8 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
                 else {
                     if (!REV) r.mode = ok ? (rev_needed(b, r.score1) ? IPX_MODE_BYTE_PLAIN : IPX_MODE_BYTE) : (b.exact_direct ? IPX_MODE_NEED_BYTE_EXACT_P : IPX_MODE_NEED_BYTE_LOW_CMP);
                     else {
-                        r.mode = IPX_MODE_BYTE;                      // certified: final; otherwise the stepped reverse pass decides
+                        // certified: final (and score1 is the plain optimum: k_tb_list may use that); otherwise the stepped reverse pass decides
+                        r.mode = (ok && (7 & b.flag) != 0) ? IPX_MODE_BYTE_OPT : IPX_MODE_BYTE;
                         if (!ok) { r.ref_begin1 = -1; r.read_begin1 = -1; }
                     }
                     b.res[i] = r;
@@ -2467,7 +2468,7 @@ IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
 // ------------------------------------------------------------------------------------------------
 IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
 {
-    if (r.mode != IPX_MODE_BYTE && r.mode != IPX_MODE_WORD) return false;
+    if (r.mode != IPX_MODE_BYTE && r.mode != IPX_MODE_WORD && r.mode != IPX_MODE_BYTE_OPT) return false;
     if (!rev_needed(b, r.score1)) return false;
     if ((7 & b.flag) == 0) return false;
     if ((2 & b.flag) != 0 && r.score1 < b.filters) return false;
@@ -2487,6 +2488,11 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
 // one and ties go to the diagonal (ssw.c:663), and the walk back from the corner (ssw.c:673-733) never leaves it: (n)M by the tail rule
 // (ssw.c:734-751).  The job gets that CIGAR here and appears in no traceback list.  (A prefix sum cannot be negative either: dropping
 // the prefix would beat the optimum.)
+// The argument needs score1 to BE the optimum of the plain recurrence.  That holds for gap_open > gap_ext and a 16-bit result, an 8-bit
+// result below 128 (no carry reaches the signed compare, ssw.c:311) or one certified against the plain recurrence (IPX_MODE_BYTE_OPT); an
+// 8-bit score of 128 or more from the stepped passes may lie BELOW the optimum (the reference's loop can stop early), and so may any
+// result under gap_open <= gap_ext (textbook 50, reference 49) -- the banded DP can then beat the diagonal through an
+// insertion / deletion pair and the reference's walk leaves it: those jobs keep the traceback kernels.
 IPX_DEV bool tb_ungapped(const IpxBatch &b, const IpxResult &r, int64_t i, int n, const uint64_t *coltab)
 {
     const int8_t *rd = b.reads + b.read_off[i] + r.read_begin1;
@@ -2519,11 +2525,14 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
             cls[k] = -1;
             if (i < b.n_jobs) {
                 IpxResult r = b.res[i];
+                const bool opt = r.mode == IPX_MODE_BYTE_OPT;
+                if (opt) { r.mode = IPX_MODE_BYTE; ((volatile uint8_t *)&b.res[i].mode)[0] = IPX_MODE_BYTE; }
                 if (cigar_needed(b, r)) {
                     const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
+                    const bool exact_opt = b.gap_open[i] > b.gap_ext[i] && (r.mode == IPX_MODE_WORD || opt || r.score1 < 128);
                     const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
                     cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : IPX_TBF_MAXBW;   // (all_general: a small batch, one wave per job)
-                    if (ungapped && bw == 1 && readLen > 0 && r.ref_begin1 >= 0 && r.read_begin1 >= 0 && tb_ungapped(b, r, i, readLen, coltab)) {
+                    if (ungapped && exact_opt && bw == 1 && readLen > 0 && r.ref_begin1 >= 0 && r.read_begin1 >= 0 && tb_ungapped(b, r, i, readLen, coltab)) {
                         const uint32_t off = atomic_add_u32(b.cigar_cursor, 1u);
                         if (off + 1u > b.cigar_cap) atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL);
                         else {

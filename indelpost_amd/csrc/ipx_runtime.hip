@@ -296,7 +296,9 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     const int64_t read_bytes = read_off[n_jobs], ref_bytes = ref_off[n_refs];
     // host-side geometry: packed (4-byte aligned, padded) window offsets and the batch maxima
     if (c->async_io) HIPCHK(hipStreamSynchronize(c->stream));   // (the previous upload's copies read h_refp / h_rlen)
-    // Everything is validated into locals first: a rejected upload leaves the resident batch (and its plans) as they were.
+    // Everything is validated into locals first: an upload rejected by VALIDATION leaves the resident batch (and its plans) as they were.
+    // Past that point buffers are reallocated and overwritten: an upload that fails there (allocation, copy) leaves the context with NO
+    // resident batch (n_jobs = 0: ipx_run then does nothing) rather than new dimensions over partly stale buffers.
     std::vector<int64_t> refp((size_t)n_refs + 1, 0);
     std::vector<int32_t> rlen((size_t)n_refs + 1, 0);
     std::vector<IpxDims> dloc(1);
@@ -322,7 +324,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->static_valid = false;
     // launch sizes learned from the previous run only carry over to a batch of similar size
     if (c->prev_valid && (n_jobs > 2 * c->n_jobs || 2 * n_jobs < c->n_jobs)) c->prev_valid = false;
-    c->n_jobs = n_jobs; c->n_refs = n_refs; c->have_mask = mask_len != nullptr;
+    c->n_jobs = 0; c->n_refs = 0; c->batch.n_jobs = 0;           // (committed at the end, when every allocation and copy has been issued)
+    c->have_mask = mask_len != nullptr;
 
     if (c->reads.ensure((size_t)read_bytes + 64) || c->read_off.ensure(8 * ((size_t)n_jobs + 1)) ||
         c->refs_raw.ensure((size_t)ref_bytes + 64) || c->ref_off.ensure(8 * ((size_t)n_refs + 1)) ||
@@ -447,6 +450,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     b.plan_counts = c->ws.plan_tables;
     b.maxcol_scratch = c->maxcol.as<uint32_t>();
     if (!c->async_io) HIPCHK(hipStreamSynchronize(s));
+    c->n_jobs = n_jobs; c->n_refs = n_refs;
     return IPX_OK;
 }
 
@@ -724,6 +728,53 @@ void ipx_cigar_hashes(const ipx_result *rec, const uint32_t *cigar_pool, int64_t
         for (int k = 0; k < rec[i].cigar_len; ++k) h = (h ^ c[k]) * 16777619u;
         out[i] = h;
     }
+}
+
+// XXH64 (Yann Collet's published algorithm, seed 0) of the batch's results in job order: per job ten little-endian int64 -- score1,
+// score2, ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, flag, cigar_len and the FNV-1a hash of its CIGAR ops (ipx_cigar_hashes).
+// This is the digest bench.py compares with the reference's (tests/golden/bench_digests.json); computed here so that the bench path needs
+// no third-party hashing package (tests/test_host_logic.py checks it against the `xxhash` package where that is installed).
+static inline uint64_t xxh_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t xxh_round(uint64_t acc, uint64_t in) { return xxh_rotl(acc + in * 0xC2B2AE3D27D4EB4FULL, 31) * 0x9E3779B185EBCA87ULL; }
+static inline uint64_t xxh_merge(uint64_t h, uint64_t v) { return (h ^ xxh_round(0, v)) * 0x9E3779B185EBCA87ULL + 0x85EBCA77C2B2AE63ULL; }
+uint64_t ipx_record_digest(const ipx_result *rec, const uint32_t *cigar_hash, int64_t n)
+{
+    const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    const uint64_t total = (uint64_t)n * 80u;
+    uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+    uint64_t buf[4];                                             // words waiting for a full 32-byte stripe
+    int nb = 0;
+    uint64_t h;
+    auto word = [&](int64_t i, int k) -> uint64_t {
+        const ipx_result &r = rec[i];
+        int64_t v;
+        switch (k) {
+        case 0: v = r.score1; break;
+        case 1: v = r.score2; break;
+        case 2: v = r.ref_begin1; break;
+        case 3: v = r.ref_end1; break;
+        case 4: v = r.read_begin1; break;
+        case 5: v = r.read_end1; break;
+        case 6: v = r.ref_end2; break;
+        case 7: v = r.flag; break;
+        case 8: v = r.cigar_len; break;
+        default: v = (int64_t)cigar_hash[i]; break;
+        }
+        return (uint64_t)v;
+    };
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 10; ++k) {
+            buf[nb++] = word(i, k);
+            if (nb == 4) { v1 = xxh_round(v1, buf[0]); v2 = xxh_round(v2, buf[1]); v3 = xxh_round(v3, buf[2]); v4 = xxh_round(v4, buf[3]); nb = 0; }
+        }
+    if (total >= 32) {
+        h = xxh_rotl(v1, 1) + xxh_rotl(v2, 7) + xxh_rotl(v3, 12) + xxh_rotl(v4, 18);
+        h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+    } else h = P5;                                               // (seed 0)
+    h += total;
+    for (int k = 0; k < nb; ++k) { h ^= xxh_round(0, buf[k]); h = xxh_rotl(h, 27) * P1 + P4; }   // (the input is whole 8-byte words: no 4- or 1-byte tail)
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
 }
 
 uint64_t ipx_synth_reads(uint64_t state, const int8_t *ref, int32_t wl, int8_t *reads, int64_t n, int32_t rl)

@@ -38,6 +38,8 @@ enum {
     IPX_MODE_NEED_BYTE_LOW_CMP = 13,  // proof failed: the lower-bound stage runs and is compared with the plain outputs in the record
     IPX_MODE_NEED_REV_PROOF = 14,
     IPX_MODE_NEED_BYTE_EXACT_P = 15,  // as NEED_BYTE_EXACT with the plain recurrence's outputs in the record: equal exact outputs keep the plain reverse pass  // begin position from the plain reverse recurrence in the record; its cell still needs the proof
+    IPX_MODE_BYTE_OPT = 16,  // final 8-bit record (both passes done) whose score1 is KNOWN to be the plain recurrence's optimum (certified by k_prove_plain);
+                             //   transient: k_tb_list, its only reader (the ungapped shortcut needs an exact optimum), turns it into IPX_MODE_BYTE
     IPX_MODE_PENDING = 255,  // not processed yet
 };
 

@@ -300,3 +300,25 @@ def test_pinned_output_bookkeeping_of_the_multi_stream_aligner(emu):
     small = m.align(a)                                                   # falls back to the blocking download
     assert all(small.as_dict(i) == plain_a.as_dict(i) for i in range(10)) and small.records is not m._out[0][0]
     m.close()
+
+
+def test_record_digest_is_xxh64(hip_lib):
+    """ipx_record_digest (the library's host-side XXH64 over ten int64 per job) equals the `xxhash` package's XXH64 of the same bytes --
+    the definition tests/golden/bench_digests.json was generated under -- for every stripe remainder (n jobs x 80 bytes mod 32)"""
+    xxhash = pytest.importorskip("xxhash")
+    from indelpost_amd.batch import record_digest
+    from indelpost_amd._lib import RESULT_DTYPE
+    rng = np.random.default_rng(31)
+    for n in (0, 1, 2, 3, 4, 5, 7, 64, 1001):
+        rec = np.zeros(n, RESULT_DTYPE)
+        for f in ("score1", "score2", "cigar_len"):
+            rec[f] = rng.integers(0, 65536, n)
+        for f in ("ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2"):
+            rec[f] = rng.integers(-1, 40000, n)
+        rec["flag"] = rng.integers(0, 3, n)
+        ch = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        m = np.empty((n, 10), np.int64)
+        for k, f in enumerate(("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2", "flag", "cigar_len")):
+            m[:, k] = rec[f]
+        m[:, 9] = ch
+        assert record_digest(rec, ch) == xxhash.xxh64(np.ascontiguousarray(m, "<i8").tobytes()).intdigest(), n
