@@ -128,28 +128,49 @@ def run_sharded(ip, args, dist, rank, world, my_devices, aligner_cls):
         g.balance_by_cells = True                                # stream slices of near-equal work, not near-equal job count
         pinned.append(bool(g.pin_host(chunks[k])) if hasattr(g, "pin_host") else False)   # staging buffers page-locked once, reused every step
 
-    def step():
-        parts = {}
+    gather_s = [0.0]
+
+    def submit():
         for g, k in zip(aligners, mine):
             g.submit(chunks[k])                                  # slice by slice: copy in, launch the pipeline; no waiting
-        for g, k in zip(aligners, mine):
-            parts[k] = g.collect()                               # slice by slice: wait, copy out (the later slices still compute)
-        if dist is not None:                                     # host-side gather on rank 0 (no data-path collective on the GPUs)
-            got = gather_bytes(dist, rank, world, [parts[rank].records.view(np.uint8).reshape(-1), np.ascontiguousarray(parts[rank].cigar_pool).view(np.uint8)])
-            if rank != 0:
-                return None
-            ordered = [BatchResult(r.view(RESULT_DTYPE), p.view(np.uint32)) for r, p in got]
-        else:
-            ordered = [parts[k] for k in range(n_parts)]
-        return merge_results(ordered)
 
-    for _ in range(max(1, args.warmup)):
-        step()
+    def collect():
+        return {k: g.collect() for g, k in zip(aligners, mine)}  # slice by slice: wait, copy out (the later slices still compute)
+
+    def gather(parts):
+        """host-side gather on rank 0 (no data-path collective on the GPUs); timed on its own (gather_ms_per_step)"""
+        t_ = time.perf_counter()
+        try:
+            if dist is not None:
+                got = gather_bytes(dist, rank, world, [parts[rank].records.view(np.uint8).reshape(-1), np.ascontiguousarray(parts[rank].cigar_pool).view(np.uint8)])
+                if rank != 0:
+                    return None
+                ordered = [BatchResult(r.view(RESULT_DTYPE), p.view(np.uint32)) for r, p in got]
+            else:
+                ordered = [parts[k] for k in range(n_parts)]
+            return merge_results(ordered)
+        finally:
+            gather_s[0] += time.perf_counter() - t_
+
+    def steps(n):
+        """n steps; the gather of step s runs while the GPUs compute step s + 1 (results sit in one of two pinned buffer pairs per
+        aligner, so the records of step s stay valid until step s + 2 is collected); the last gather is inside the timed region too"""
+        res_, prev = None, None
+        for _ in range(n):
+            submit()
+            if prev is not None:
+                res_ = gather(prev)
+            prev = collect()
+        if prev is not None:
+            res_ = gather(prev)
+        return res_
+
+    steps(max(1, args.warmup))
     if dist is not None:
         dist.barrier()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = steps(args.steps)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -168,7 +189,9 @@ def run_sharded(ip, args, dist, rank, world, my_devices, aligner_cls):
         out = {"metric": "million read-alignments/sec (150 bp x 300 bp, affine gap)", "mode": "sharded",
                "value": round(jobs_total * args.steps / elapsed / 1e6, 6), "unit": "million alignments/s",
                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "gather_ms_per_step": round(gather_s[0] / args.steps * 1e3, 4),    # rank 0's host-side gather + merge, overlapped with the next step's kernels
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": "f16 (16-bit passes and the plain 8-bit recurrence: packed halves, exact for these integers) / int16 (stepped 8-bit passes)",
                "data": "synthetic",

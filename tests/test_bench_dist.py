@@ -36,3 +36,19 @@ def test_two_rank_gloo_shard_and_gather(emu, tmp_path):
     p = _torchrun([os.path.join(ROOT, "tests", "dist_worker.py"), str(out)], 29517)
     assert p.returncode == 0, p.stderr[-2000:]
     assert out.read_text().startswith("OK 14")
+
+
+def test_single_process_bench_drives_every_gpu_from_its_own_host_thread(emu, hip_lib):
+    """plain `python bench.py --gpus N` (no torchrun): one host thread per GPU issues that GPU's steps; rehearsed on the emulator.  The
+    line names the threads and the measured enqueue cost per GPU, and shard 0's results are those of the one-GPU run."""
+    def run(n):
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "emu", "--steps", "2", "--warmup", "1",
+                            "--reads-per-gpu", "48", "--no-cpu-baseline", "--no-subconfigs", "--streams", "2"], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, p.stdout[-2000:]
+        return json.loads(line[0])
+    one, three = run(1), run(3)
+    assert three["n_gpus"] == 3 and three["host_threads"] == 3 and len(three["host_enqueue_ms_per_step"]) == 3
+    assert one["host_threads"] == 1 and three["sum_score1"] == one["sum_score1"] > 0
