@@ -52,6 +52,11 @@ IPX_DEV int lane_id() { return IPX_TID & 63; }
 // lane i <- lane i-1 inside its 16-lane row, first lane of the row <- 0   (DPP row_shr:1)
 IPX_DEV uint32_t xl_row_shr1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) ? (IPX_TID - 1) : -1); }
 template <int N> IPX_DEV uint32_t xl_row_shr(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) >= N ? (IPX_TID - N) : -1); }
+// lane i <- lane i+1 inside its 16-lane row, last lane of the row <- 0   (DPP row_shl:1)
+IPX_DEV uint32_t xl_row_shl1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, (l & 15) != 15 ? (IPX_TID + 1) : -1); }
+// the same across the whole wavefront (DPP wave_shr:1 / wave_shl:1, GFX9): lane i <- lane i-1 (lane 0 <- 0) / lane i <- lane i+1 (lane 63 <- 0)
+IPX_DEV uint32_t xl_wave_shr1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, l > 0 ? (IPX_TID - 1) : -1); }
+IPX_DEV uint32_t xl_wave_shl1(uint32_t v) { int l = lane_id(); return ipx_emu::exchange(v, l < 63 ? (IPX_TID + 1) : -1); }
 IPX_DEV uint32_t xl_xor1(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 1); }   // quad_perm [1,0,3,2]
 IPX_DEV uint32_t xl_xor2(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 2); }   // quad_perm [2,3,0,1]
 IPX_DEV uint32_t xl_half_mirror(uint32_t v) { return ipx_emu::exchange(v, IPX_TID ^ 7); }  // row_half_mirror
@@ -181,6 +186,11 @@ template <int LANE> IPX_DEV uint32_t xl_readlane(uint32_t v) { return (uint32_t)
 // row_mirror = 0x140, row_half_mirror = 0x141.  bound_ctrl=1 -> out-of-row source reads 0.
 IPX_DEV uint32_t xl_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
 template <int N> IPX_DEV uint32_t xl_row_shr(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true); }   // row_shr:N
+IPX_DEV uint32_t xl_row_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }    // row_shl:1
+// whole-wavefront shifts (wave_shr:1 = 0x138, wave_shl:1 = 0x130; GFX9 DPP controls, present on gfx950: tools/ubench_dpp.hip -- same
+// cost as a row shift)
+IPX_DEV uint32_t xl_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+IPX_DEV uint32_t xl_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 IPX_DEV uint32_t xl_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 IPX_DEV uint32_t xl_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
 IPX_DEV uint32_t xl_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); }

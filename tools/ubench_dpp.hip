@@ -27,17 +27,21 @@ __global__ void sem(uint32_t *out)
     uint32_t a = threadIdx.x + 100;
     out[threadIdx.x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x138, 0xf, 0xf, true);
     out[64 + threadIdx.x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x111, 0xf, 0xf, true);
+    out[128 + threadIdx.x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x130, 0xf, 0xf, true);
+    out[192 + threadIdx.x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x101, 0xf, 0xf, true);
 }
 int main()
 {
     uint32_t *out; uint64_t *rec;
     (void)hipMalloc(&out, 1024 * 64 * 4);
     (void)hipMalloc(&rec, 1024 * 16);
-    uint32_t h[128];
+    uint32_t h[256];
     hipLaunchKernelGGL(sem, dim3(1), dim3(64), 0, 0, out);
-    (void)hipMemcpy(h, out, 512, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, out, 1024, hipMemcpyDeviceToHost);
     printf("wave_shr:1 :"); for (int i = 0; i < 64; ++i) printf(" %u", h[i]); printf("\n");
     printf("row_shr:1  :"); for (int i = 0; i < 64; ++i) printf(" %u", h[64 + i]); printf("\n");
+    printf("wave_shl:1 :"); for (int i = 0; i < 64; ++i) printf(" %u", h[128 + i]); printf("\n");
+    printf("row_shl:1  :"); for (int i = 0; i < 64; ++i) printf(" %u", h[192 + i]); printf("\n");
     for (int kind = 0; kind < 4; ++kind) {
         if (kind == 2) continue;
         uint64_t r[2];
