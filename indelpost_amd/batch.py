@@ -19,7 +19,7 @@ _OPS = "MIDNSHP=X"
 # identical results -- the tests run them all
 ROUTE_NO_WORD_FIRST, ROUTE_NO_PERM_PROFILE, ROUTE_NO_BRACKET, ROUTE_TB_NO_FUSE, ROUTE_NO_MC_LDS, ROUTE_NO_F16, ROUTE_NO_SKEW, ROUTE_NO_VL2 = 1, 2, 4, 8, 16, 32, 64, 128
 ROUTE_NO_PLAIN_FIRST, ROUTE_NO_CLASS_MERGE, ROUTE_NO_TIERS, ROUTE_NO_EXACT_DIRECT, ROUTE_TB_NO_WAVE_PER_JOB = 256, 512, 1024, 2048, 4096
-ROUTE_TB_NO_UNGAPPED = 8192
+ROUTE_TB_NO_UNGAPPED, ROUTE_TB_NO_DIAG = 8192, 16384
 
 # DNA_BASE_LUT of the reference (sswpy.pyx:16-25): A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, else 4.
 # Bytes >= 128 index the reference's table out of bounds (undefined); they map to N here.
@@ -443,8 +443,9 @@ class GpuAligner:
         return out
 
     def traceback_routing(self):
-        """jobs per first band width 1..7, jobs handed to the general kernel, jobs handed to the wide-band kernel"""
-        out = np.zeros(9, np.uint32)
+        """jobs of the last run per traceback list: [0..6] lane-per-job kernels, first band 1..7 (doubled bands included); [7] the
+        wave-per-job kernel (k_tb_coop); [8..10] the anti-diagonal tiers of 16 / 32 / 64 lanes per job (k_tb_diag); [11] 0"""
+        out = np.zeros(12, np.uint32)
         self._check(self._L.ipx_debug_tb_counts(self._ctx, _p(out)), "ipx_debug_tb_counts")
         return out.tolist()
 

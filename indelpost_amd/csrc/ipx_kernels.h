@@ -2480,6 +2480,8 @@ IPX_DEV bool cigar_needed(const IpxBatch &b, const IpxResult &r)
 // register/LDS-resident kernel k_tb_fast<BW> (list BW-1 = lists + (BW-1)*n_jobs, counter BW-1), wider
 // ones straight to the general kernel (list 7 = `esc`, counter 7).
 #define IPX_TBF_MAXBW 7
+#define IPX_TBD_ROWS 256          // (k_tb_diag) longest aligned read span the anti-diagonal tiers take (longer jobs: k_tb_coop)
+#define IPX_TBD_CIG 64            // (k_tb_diag) CIGAR runs of a job held in LDS (more: k_tb_coop)
 // r03, UNGAPPED alignments: when refLen == readLen (first band 1) and the scores on the rectangle's diagonal add up to score1, the
 // CIGAR is one run of M and banded_sw's DP is not needed to know it.  Why: every value of banded_sw's matrix is the score of a local
 // alignment inside the rectangle (floors at 0, ssw.c:655-656), hence <= score1, the optimum.  Were H at some diagonal cell larger than
@@ -2505,6 +2507,13 @@ IPX_DEV bool tb_ungapped(const IpxBatch &b, const IpxResult &r, int64_t i, int n
     }
     return u == (int)r.score1;
 }
+// r04: with the anti-diagonal tiers (IpxBatch::tb_diag, k_tb_diag) the classes are 0..6 = lane-per-job widths 1..7, 7 = k_tb_coop (`esc`),
+// 8 / 9 / 10 = the tiers of 16 / 32 / 64 lanes per job (first band <= 15 / 31 / 63; lists 7 / 8 / 9 of `lists`, counters 8 / 9 / 10).  A SMALL batch
+// (`all_general`) has more SIMDs than jobs: every job takes a tier -- a quarter of a wave at least -- instead of one lane.
+#define IPX_TB_CLS_COOP 7
+#define IPX_TB_CLS_DIAG 8
+#define IPX_TB_NLISTS 10          // lists of n_jobs entries in IpxWorkspace::tb_list (7 widths + 3 tiers; k_tb_coop's list is IpxWorkspace::tb_esc)
+#define IPX_TB_NCOUNTERS 12
 IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc, int all_general, int ungapped)
 {
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
@@ -2531,7 +2540,12 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                     const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
                     const bool exact_opt = b.gap_open[i] > b.gap_ext[i] && (r.mode == IPX_MODE_WORD || opt || r.score1 < 128);
                     const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-                    cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : IPX_TBF_MAXBW;   // (all_general: a small batch, one wave per job)
+                    if (b.tb_diag) {
+                        b.tb_bw[i] = 0;                                                        // (every tier starts the job from its own first band)
+                        const int tier = (readLen > IPX_TBD_ROWS || readLen < 1 || refLen < 1) ? IPX_TB_CLS_COOP
+                                         : bw <= 15 ? IPX_TB_CLS_DIAG : bw <= 31 ? IPX_TB_CLS_DIAG + 1 : bw <= 63 ? IPX_TB_CLS_DIAG + 2 : IPX_TB_CLS_COOP;
+                        cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : tier;
+                    } else cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : IPX_TB_CLS_COOP;   // (all_general: a small batch, one wave per job)
                     if (ungapped && exact_opt && bw == 1 && readLen > 0 && r.ref_begin1 >= 0 && r.read_begin1 >= 0 && tb_ungapped(b, r, i, readLen, coltab)) {
                         const uint32_t off = atomic_add_u32(b.cigar_cursor, 1u);
                         if (off + 1u > b.cigar_cap) atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL);
@@ -2552,7 +2566,8 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
             const int64_t i = q * stride + (int64_t)IPX_BID * chunk + (int64_t)k * IPX_BDIM + IPX_TID;
             if (cls[k] >= 0) {
                 if (cls[k] < IPX_TBF_MAXBW) lists[(int64_t)cls[k] * b.n_jobs + slot[k]] = (uint32_t)i;
-                else esc[slot[k]] = (uint32_t)i;
+                else if (cls[k] == IPX_TB_CLS_COOP) esc[slot[k]] = (uint32_t)i;
+                else lists[(int64_t)(cls[k] - 1) * b.n_jobs + slot[k]] = (uint32_t)i;
             }
         }
     }
@@ -2628,7 +2643,7 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
         const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
         const int len = refLen > readLen ? refLen : readLen;
         bool esc = (!retried && bw != BW) || readLen > rowcap;
-        bool widen = false;
+        bool widen = false, todiag = false;
         int mx = 0;
         if (!esc) {
             int hb[W + 1], eb[W + 1], hc[W + 1];                        // fresh arrays (ssw.c:607-609, 627)
@@ -2702,12 +2717,14 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
                 for (int q = 1; q <= WD; ++q) if (q <= nact) hb[q] = hc[q];   // ssw.c:666
             }
             if (mx < score && BW * 2 <= len) {                          // band would double (ssw.c:668-669)
-                if (WIDEN && 2 * BW <= IPX_TBF_MAXBW) widen = true; else esc = true;
+                if (WIDEN && 2 * BW <= IPX_TBF_MAXBW) widen = true;
+                else if (b.tb_diag && readLen <= IPX_TBD_ROWS) todiag = true;   // the band of 2 * BW: the anti-diagonal tiers (k_tb_diag) start there
+                else esc = true;
             }
         }
         int lcnt = 0, e = 0, op = 0;
         bool fail = false;
-        if (!esc && !widen) {
+        if (!esc && !widen && !todiag) {
             // ---- trace back (ssw.c:673-751) ----
             // the walk moves up one row at most per step: keep the words of rows i and i-1 in registers and
             // fetch row i-2 as soon as the walk moves (a cell index outside those two rows reads memory)
@@ -2752,8 +2769,13 @@ IPX_DEV void tb_fast_body(const IpxBatch &b, const uint32_t *list, const uint32_
             lists_base[(int64_t)(NB - 1) * b.n_jobs + atomic_add_u32(&counters[NB - 1], 1u)] = (uint32_t)jb | 0x80000000u;
             continue;
         }
+        if (todiag) {
+            b.tb_bw[jb] = (uint16_t)(2 * BW);
+            lists_base[(int64_t)(IPX_TB_CLS_DIAG - 1) * b.n_jobs + atomic_add_u32(&counters[IPX_TB_CLS_DIAG], 1u)] = (uint32_t)jb;
+            continue;
+        }
         if (fail && retried) esc = true;                               // (see WIDEN above)
-        if (esc) { next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb; continue; }
+        if (esc) { if (b.tb_diag) b.tb_bw[jb] = 0; next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb; continue; }
         if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; continue; }                // ssw.c:911
         if (op == 0) { ++lcnt; cig[(lcnt - 1) * 64] = ((uint32_t)(e + 1) << 4); }          // ssw.c:734-751
         else { lcnt += 2; cig[(lcnt - 2) * 64] = ((uint32_t)e << 4) | (uint32_t)op; cig[(lcnt - 1) * 64] = (1u << 4); }
@@ -2861,8 +2883,14 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
         const int gapO = b.gap_open[jb], gapE = b.gap_ext[jb];
         const int g = gapO < gapE ? gapO : gapE;
         const int score = r.score1;
-        int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
         const int len = refLen > readLen ? refLen : readLen;
+        // r04: a job handed over by an anti-diagonal tier (k_tb_diag) starts at the band that tier could not hold (IpxBatch::tb_bw): the
+        // narrower iterations are known to end in "max < score", and all they leave behind are stale direction cells, which matter only if
+        // the walk back reads a cell the last iteration has not written -- then (`redo`) the job is run again from its first band, as the
+        // reference does it
+        int start = b.tb_diag ? (int)b.tb_bw[jb] : 0;
+        for (;;) {
+        int bw = start ? start : (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
         int mx = 0, width = 0, width_d = 0, extent = 0;
         bool broken = false;
         // band rows: LDS when 2 * len + 8 entries fit there, else this block's region of the global scratch
@@ -2999,11 +3027,12 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
             mx = (int)wave_umax((uint32_t)mx);                                             // every lane saw only its own cells
             bw *= 2;
         } while (mx < score && bw <= len);                                                // ssw.c:669
-        if (broken) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH); continue; }
+        if (broken) { if (lane == 0) atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH); break; }
         bw /= 2;
 
         // ---- trace back (ssw.c:673-751), lane 0 ----
         IPX_SYNC();
+        int redo = 0;
         if (lane == 0) {
             int i = readLen - 1, j = refLen - 1, e = 0, lcnt = 0, plane = 2, op = 0, prev = 0;
             bool fail = false, full = false;
@@ -3034,6 +3063,7 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
                 }
             }
             if (full) atomic_or_u32(b.status, IPX_STATUS_TB_SCRATCH);
+            else if (fail && start != 0) redo = 1;
             else if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; }                 // ssw.c:911
             else {
                 if (op == 0) { ++lcnt; cig[lcnt - 1] = ((uint32_t)(e + 1) << 4); }         // ssw.c:734-751
@@ -3048,7 +3078,229 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
                 }
             }
         }
+        redo = (int)xl_first((uint32_t)redo);
         IPX_SYNC();
+        if (!redo) break;
+        start = 0;
+        }
+    }
+}
+// ------------------------------------------------------------------------------------------------
+// k_tb_diag<LG> (r04): banded_sw (ssw.c:588-772) as an ANTI-DIAGONAL WAVEFRONT, LG = 16 / 32 / 64 lanes per job (4 / 2 / 1 jobs per wave).
+// The tiers between the lane-per-job kernels (first band <= 7, no help for a small batch: one lane walks a whole job) and the
+// wave-per-job kernel (k_tb_coop: three barriers and a scan over 64 lanes per DP row, whatever the band): bands of half-width
+// 8..15 / ..31 / ..63, and EVERY job of a small batch.
+//   Lane k of a job's group owns the band diagonals q = 2k and 2k+1 (q = j - i + bw, 0..2bw: up to LG - 1 = bw).  A cell (i, q) sits on
+//   anti-diagonal tau = 2i + q; at step tau lane k works on row i = tau / 2 - k of diagonal 2k + (tau & 1).  Everything a cell needs is
+//   one or two steps old: the upper neighbour (i-1, q+1) and the left one (i, q-1) are on anti-diagonal tau - 1 -- in the lane's own
+//   other diagonal, or in the neighbouring lane's (one DPP shift) -- the diagonal one (i-1, q) on tau - 2 in the lane's own registers.
+//   So a step is straight-line code without any scan, barrier or memory dependency: 2 * rows + 2 * bw steps for a band, H / E / F of
+//   the last two anti-diagonals in six registers per lane.
+//   Out-of-band and out-of-rectangle neighbours read 0, as the reference's h_b / e_b / h_c arrays do (ssw.c:627, 633) -- with the
+//   reference's one irregularity kept: `h_b[edge] = e_b[edge] = 0` (ssw.c:632-633) wipes the upper neighbour of the LAST window column in
+//   rows 1..bw+1 when the window is no wider than the band arrays (refLen <= 2bw + 2) although that neighbour is inside the band.  (The
+//   formulation "cell by cell with these neighbour rules" was checked against a literal transcription of the reference's loops on 40 000
+//   random rectangles before the kernel was written.)
+//   Directions: one nibble per cell (k_tb_fast's code: 0 = never written, else 1 + 4 * Hsrc + 2 * Fopen + Eopen), eight steps = four rows
+//   x two diagonals per 32-bit word, words in LDS [hi / 4][lane] with hi = row + lane: the walk back (lane 0 of the group, ssw.c:673-751)
+//   finds cell (row, slot) -- the reference's linear cell index, so out-of-band reads alias as there -- at lane q / 2, word (row + lane) / 4.
+//   Only the LAST band iteration's cells exist here: a walk that meets an unwritten cell after an earlier, narrower iteration (in this
+//   kernel or a previous tier) hands the job to k_tb_coop, which keeps the reference's one buffer across iterations; without an earlier
+//   iteration an unwritten cell is the reference's "Trace back error" (flag 1), as everywhere.
+//   A band that outgrows the tier (max < score, ssw.c:669, and 2bw > LG - 1) is handed to the next tier with the band to start from
+//   (IpxBatch::tb_bw): the narrower iterations' only lasting effect is the stale cells the previous paragraph deals with.
+// Dynamic LDS: 64 B score table | per group: read letters IPX_TBD_ROWS | window letters IPX_TBD_ROWS + LG | direction words | IPX_TBD_CIG runs
+// ------------------------------------------------------------------------------------------------
+IPX_HD constexpr int ipx_tbd_group_bytes(int lg) { return IPX_TBD_ROWS + (IPX_TBD_ROWS + lg) + ((IPX_TBD_ROWS + lg) / 4) * lg * 4 + IPX_TBD_CIG * 4; }
+IPX_HD constexpr int ipx_tbd_lds_bytes(int lg) { return 64 + (64 / lg) * ipx_tbd_group_bytes(lg); }
+
+template <int LG> IPX_DEV uint32_t tbd_from_lower(uint32_t v, int k)      // lane k <- lane k-1 of the group, first lane <- 0
+{
+    if (LG == 16) return xl_row_shr1(v);
+    const uint32_t y = xl_wave_shr1(v);
+    return k == 0 ? 0u : y;
+}
+template <int LG> IPX_DEV uint32_t tbd_from_upper(uint32_t v, int k)      // lane k <- lane k+1 of the group, last lane <- 0
+{
+    if (LG == 16) return xl_row_shl1(v);
+    const uint32_t y = xl_wave_shl1(v);
+    return k == LG - 1 ? 0u : y;
+}
+template <int LG> IPX_DEV uint32_t tbd_group_umax(uint32_t x)
+{
+    if (LG == 16) return group_umax<16>(x);
+    for (int s = 1; s < LG; s <<= 1) { const uint32_t y = xl_shfl(x, lane_id() ^ s); x = x > y ? x : y; }
+    return x;
+}
+
+template <int LG>
+IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t *list_n, uint32_t *next, uint32_t *next_n, uint32_t *coop, uint32_t *coop_n)
+{
+    constexpr int NG = 64 / LG, ROWS = IPX_TBD_ROWS, REFCAP = ROWS + LG, NW = (ROWS + LG) / 4, GB = ipx_tbd_group_bytes(LG);
+    const int lane = lane_id(), k = lane % LG, grp = lane / LG;
+    unsigned char *lds = IPX_LDS_BASE;
+    uint64_t *coltab = (uint64_t *)lds;                             // [read letter a] -> bytes mat[c][a], c = 0..4
+    int8_t *sread = (int8_t *)(lds + 64 + grp * GB);
+    int8_t *sref = sread + ROWS;
+    uint32_t *dirw = (uint32_t *)(sref + REFCAP);                   // [hi / 4][lane of the group]
+    uint32_t *cig = dirw + NW * LG;
+    if (lane < 5) {
+        uint64_t t = 0;
+        for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
+        coltab[lane] = t;
+    }
+    IPX_SYNC();
+    const uint32_t n = *list_n;
+
+    for (uint32_t base = (uint32_t)IPX_BID * NG; base < n; base += (uint32_t)IPX_GDIM * NG) {      // (uniform: n > 0 inside)
+        const uint32_t item = base + (uint32_t)grp;
+        const bool has = item < n;
+        const int64_t jb = has ? (int64_t)list[item] : (int64_t)list[base];
+        IpxResult r = b.res[jb];
+        const int rid = b.ref_id[jb];
+        const int fullRef = b.ref_len[rid];
+        const int8_t *refp = b.refs_packed + b.refp_off[rid];
+        const int8_t *readp = b.reads + b.read_off[jb] + r.read_begin1;
+        const int rb = r.ref_begin1;
+        const int refLen = r.ref_end1 - r.ref_begin1 + 1;             // ssw.c:897-899
+        const int readLen = r.read_end1 - r.read_begin1 + 1;
+        const int gapO = b.gap_open[jb], gapE = b.gap_ext[jb];
+        const int score = r.score1;
+        const int len = refLen > readLen ? refLen : readLen;
+        const int start = b.tb_bw[jb];                                // 0: the job's own first band; else an earlier tier went up to start / 2
+        int bw = start ? start : (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+        // 0 = this tier's, 1 = hand over to the next tier (band too wide), 2 = k_tb_coop from its first band, 3 = no job in this group
+        int route = !has ? 3 : (readLen < 1 || refLen < 1 || readLen > ROWS || refLen > REFCAP) ? 2 : 0;
+        if (route == 0) {                                             // the job's letters, staged once (codes outside 0..4 -> N, ssw.c's read is sanitised by sswpy)
+            for (int q = k; q < readLen; q += LG) { const int a = readp[q]; sread[q] = (int8_t)((unsigned)a > 4u ? 4 : a); }
+            for (int q = k; q < refLen; q += LG) { const int ri = rb + q; sref[q] = (ri >= 0 && ri < fullRef) ? refp[ri] : (int8_t)0; }
+        }
+        IPX_SYNC();
+
+        bool settled = false;
+        int iters = 0;
+        for (;;) {                                                    // band iterations (ssw.c:624-669); groups that are done idle
+            bool run = route == 0 && !settled;
+            if (run && bw > LG - 1) { route = 1; run = false; }
+            if (!xl_any(run)) break;
+            const int TH = (int)xl_first(wave_umax(run ? (uint32_t)(readLen + bw) : 0u));     // hi = 0 .. readLen - 1 + bw
+            const bool quirk = refLen <= 2 * bw + 2;                  // (see above: h_b[edge] = 0 hits a cell inside the band)
+            int He = 0, Ee = 0, Fe = 0, Ho = 0, Eo = 0, Fo = 0, mx = 0;
+            uint32_t word = 0;
+            for (int hi = 0; hi < TH; ++hi) {
+                const int i = hi - k;
+                const bool rowok = run && i >= 0 && i < readLen && k <= bw;
+                const int rd = rowok ? (int)sread[i] : 0;
+                const uint64_t mrow = coltab[rd];                      // this row's scores against the five window letters
+                const int j0 = i + 2 * k - bw;
+                const bool up0 = quirk && i >= 1 && i <= bw + 1;       // rows whose last-column upper neighbour is wiped
+                // ---- even step: diagonal 2k ----
+                {
+                    const int Hl = (int)tbd_from_lower<LG>((uint32_t)Ho, k), Fl = (int)tbd_from_lower<LG>((uint32_t)Fo, k);
+                    const bool valid = rowok && j0 >= 0 && j0 < refLen;
+                    const int rc = valid ? (int)sref[j0] : 0;
+                    int Hu = Ho, Eu = Eo;
+                    if (up0 && j0 == refLen - 1) { Hu = 0; Eu = 0; }
+                    int t1 = i == 0 ? -gapO : Hu - gapO;                // ssw.c:644-648
+                    int t2 = i == 0 ? -gapE : Eu - gapE;
+                    const int ev = t1 > t2 ? t1 : t2, de = t1 > t2 ? 1 : 0;
+                    t1 = Hl - gapO; t2 = Fl - gapE;                     // ssw.c:650-653
+                    const int fv = t1 > t2 ? t1 : t2, df = t1 > t2 ? 1 : 0;
+                    const int e1 = ev > 0 ? ev : 0, f1 = fv > 0 ? fv : 0;   // ssw.c:655-664
+                    t1 = e1 > f1 ? e1 : f1;
+                    t2 = He + (int)(int8_t)(mrow >> (8 * rc));
+                    const int hv = t1 > t2 ? t1 : t2;
+                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
+                    He = valid ? hv : 0; Ee = valid ? ev : 0; Fe = valid ? fv : 0;
+                    if (valid) { if (hv > mx) mx = hv; word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (8 * (hi & 3)); }
+                }
+                // ---- odd step: diagonal 2k + 1 ----
+                {
+                    const int j1 = j0 + 1;
+                    int Hu = (int)tbd_from_upper<LG>((uint32_t)He, k), Eu = (int)tbd_from_upper<LG>((uint32_t)Ee, k);
+                    const bool valid = rowok && k < bw && j1 >= 0 && j1 < refLen;
+                    const int rc = valid ? (int)sref[j1] : 0;
+                    if (up0 && j1 == refLen - 1) { Hu = 0; Eu = 0; }
+                    int t1 = i == 0 ? -gapO : Hu - gapO;
+                    int t2 = i == 0 ? -gapE : Eu - gapE;
+                    const int ev = t1 > t2 ? t1 : t2, de = t1 > t2 ? 1 : 0;
+                    t1 = He - gapO; t2 = Fe - gapE;
+                    const int fv = t1 > t2 ? t1 : t2, df = t1 > t2 ? 1 : 0;
+                    const int e1 = ev > 0 ? ev : 0, f1 = fv > 0 ? fv : 0;
+                    t1 = e1 > f1 ? e1 : f1;
+                    t2 = Ho + (int)(int8_t)(mrow >> (8 * rc));
+                    const int hv = t1 > t2 ? t1 : t2;
+                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
+                    Ho = valid ? hv : 0; Eo = valid ? ev : 0; Fo = valid ? fv : 0;
+                    if (valid) { if (hv > mx) mx = hv; word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (8 * (hi & 3) + 4); }
+                }
+                if ((hi & 3) == 3 || hi == TH - 1) { if (run) dirw[(hi >> 2) * LG + k] = word; word = 0; }
+            }
+            mx = (int)tbd_group_umax<LG>((uint32_t)mx);
+            if (run) {
+                ++iters;
+                if (mx >= score || 2 * bw > len) settled = true;      // ssw.c:668-669
+                else bw *= 2;
+            }
+        }
+        IPX_SYNC();                                                   // direction words visible to the group's first lane
+
+        // ---- trace back (ssw.c:673-751): the group's first lane ----
+        if (k == 0 && route == 0) {
+            const int WD = 2 * bw + 1;
+            const int nwords = (readLen + bw + 3) >> 2;               // words a lane wrote in the last iteration
+            int i = readLen - 1, j = refLen - 1, e = 0, lcnt = 0, plane = 2, op = 0, prev = 0;
+            bool fail = false, full = false;
+            while (i >= 0 && j > 0) {
+                // the reference's linear cell index width_d * i + (j - x): a column outside the row's band aliases into a neighbouring row
+                int row = i, slot = j - (i - bw > 0 ? i - bw : 0);
+                while (slot < 0) { slot += WD; --row; }
+                while (slot >= WD) { slot -= WD; ++row; }
+                int code = 0;
+                if (row >= 0 && row < readLen) {
+                    const int q = slot + (bw - row > 0 ? bw - row : 0);        // band diagonal of that slot in that row
+                    const int lk = q >> 1, hh = row + lk;
+                    if (q <= 2 * bw && (hh >> 2) < nwords) {
+                        const int v = (int)((dirw[(hh >> 2) * LG + lk] >> (8 * (hh & 3) + 4 * (q & 1))) & 15u);
+                        if (v) {
+                            const int de = 2 + ((v - 1) & 1), df = 4 + (((v - 1) >> 1) & 1), dh = (v - 1) >> 2;
+                            code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
+                        }
+                    }
+                }
+                if (code == 1) { --i; --j; plane = 2; op = 0; }
+                else if (code == 2) { --i; plane = 0; op = 1; }
+                else if (code == 3) { --i; plane = 2; op = 1; }
+                else if (code == 4) { --j; plane = 1; op = 2; }
+                else if (code == 5) { --j; plane = 2; op = 2; }
+                else { fail = true; break; }
+                if (op == prev) ++e;
+                else {
+                    ++lcnt;
+                    if (lcnt + 2 > IPX_TBD_CIG) { full = true; break; }
+                    cig[lcnt - 1] = ((uint32_t)e << 4) | (uint32_t)prev;
+                    prev = op;
+                    e = 1;
+                }
+            }
+            if (full || (fail && (start != 0 || iters > 1))) route = 2;          // (stale cells of narrower iterations could matter: k_tb_coop keeps them)
+            else if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; }          // ssw.c:711-719, 911
+            else {
+                if (op == 0) { ++lcnt; cig[lcnt - 1] = ((uint32_t)(e + 1) << 4); }  // ssw.c:734-751
+                else { lcnt += 2; cig[lcnt - 2] = ((uint32_t)e << 4) | (uint32_t)op; cig[lcnt - 1] = (1u << 4); }
+                const uint32_t off = atomic_add_u32(b.cigar_cursor, (uint32_t)lcnt);
+                if (off + (uint32_t)lcnt > b.cigar_cap) atomic_or_u32(b.status, IPX_STATUS_CIGAR_POOL);
+                else {
+                    for (int q = 0; q < lcnt; ++q) b.cigar_pool[off + q] = cig[lcnt - 1 - q];   // reverse (ssw.c:754-762)
+                    r.cigar_off = off;
+                    r.cigar_len = (uint16_t)lcnt;
+                    b.res[jb] = r;
+                }
+            }
+        }
+        if (k == 0 && route == 1) { b.tb_bw[jb] = (uint16_t)bw; next[atomic_add_u32(next_n, 1u)] = (uint32_t)jb; }
+        if (k == 0 && route == 2) { b.tb_bw[jb] = 0; coop[atomic_add_u32(coop_n, 1u)] = (uint32_t)jb; }
+        IPX_SYNC();                                                   // the group's LDS is free for its next job
     }
 }
 #endif // IPX_AUX_KERNELS

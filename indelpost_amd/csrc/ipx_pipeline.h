@@ -20,7 +20,8 @@ struct IpxWorkspace {
     IpxPlan plan[IPX_NUM_PASSES];
     uint32_t *plan_tables;              // [IPX_NUM_PASSES][2][IPX_NUM_CLASSES]: count and cursor of every pass, the dynamic passes' part zeroed per run
     uint32_t *exact_starters;           // [IPX_NUM_CLASSES] jobs that START in the stepped 8-bit pass (host-known): seeds its count row every run
-    uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: 7 lists (first band 1..7) of n_jobs slots; 8 counters, the 8th = tb_esc_n
+    uint32_t *tb_list, *tb_list_n;      // jobs that get a CIGAR: IPX_TB_NLISTS lists of n_jobs slots (first band 1..7; then the anti-diagonal tiers of 16 / 32 / 64
+                                        //   lanes per job); IPX_TB_NCOUNTERS counters: [0..6] the widths, [7] = tb_esc_n, [8..10] the tiers
     uint32_t *tb_esc, *tb_esc_n;        // jobs the fast traceback hands to the general (one wave per job) kernel
     IpxTbScratch tb1;
     unsigned char *tbf_scratch;         // direction words of the fast traceback: ipx_tbf_scratch_bytes_per_block(rowcap) per block
@@ -28,12 +29,16 @@ struct IpxWorkspace {
     int64_t long_stride;
     int long_blocks;
     int tbf_waves, tb1_waves;
+    int tbd_waves;                      // blocks of a k_tb_diag launch
 };
 
 #ifndef IPX_PROVE_CHUNK_MIN_JOBS
 #define IPX_PROVE_CHUNK_MIN_JOBS 100000   // (the emulator build sets 0 so that its small batches take the queued form)
 #endif
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
+#ifndef IPX_TB_SMALL_DIAG
+#define IPX_TB_SMALL_DIAG 8192   // batches up to this many jobs: every traceback takes an anti-diagonal tier (4 jobs per wave at most) instead of a lane
+#endif
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
 #define IPX_MAX_READ_LEN IPX_LONG_MAX_READ   // longest read the library takes (beyond 8 * IPX_MAX_SEG = 512 bp: k_dp_long)
 
@@ -360,7 +365,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     for (int c = 0; c < IPX_NUM_CLASSES; ++c) { has8_all[c] = d.has8_low[c] | d.has8_wf[c]; has16_all[c] = d.has16_low[c] | d.has16_wf[c]; }
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(b.cigar_cursor, 1);
-    be.zero_u32(ws.tb_list_n, 8);
+    be.zero_u32(ws.tb_list_n, IPX_TB_NCOUNTERS);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, IPX_FIRST_DYNAMIC_PASS), (IPX_NUM_PASSES - IPX_FIRST_DYNAMIC_PASS) * 2 * IPX_NUM_CLASSES);
     if (b.score_size != 1) be.copy_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, ws.exact_starters, IPX_NUM_CLASSES);
 
@@ -450,7 +455,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             // a SMALL batch has more SIMDs than jobs: one wave per job (k_tb_coop: a DP row spread over the lanes) then finishes a typical job in
             // a fifth of the time one lane needs for it (r03, 1000 jobs: 0.76 -> 0.42 ms of traceback), and the lane-per-job launch is skipped
-            const int tb_all_general = !(routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) && b.n_jobs <= 2048;
+            const int tb_all_general = !(routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) && b.n_jobs <= (b.tb_diag ? IPX_TB_SMALL_DIAG : 2048);
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 64, b, ws.tb_list, ws.tb_list_n, ws.tb_esc, tb_all_general,
                       ((routing & IPX_ROUTE_TB_NO_UNGAPPED) || tb_all_general) ? 0 : 1);   // (a small batch has a wave for every job: the check would only add its own latency)
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
@@ -486,6 +491,15 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 }
             }
 #undef IPX_TBF_LAUNCH
+            // anti-diagonal tiers (r04): first bands 8..63, bands the lane-per-job kernels saw double past 7, and every job of a small batch; a tier
+            // hands a band it cannot hold to the next one
+            if (b.tb_diag) {
+                uint32_t *l16 = ws.tb_list + (int64_t)(IPX_TB_CLS_DIAG - 1) * b.n_jobs, *l32 = l16 + b.n_jobs, *l64 = l32 + b.n_jobs;
+                uint32_t *c16 = ws.tb_list_n + IPX_TB_CLS_DIAG;
+                be.launch(IPX_KEY(IPX_K_TRACEBACK, 16), k_tb_diag<16>, ws.tbd_waves, 64, ipx_tbd_lds_bytes(16), b, (const uint32_t *)l16, (const uint32_t *)c16, l32, c16 + 1, ws.tb_esc, ws.tb_esc_n);
+                be.launch(IPX_KEY(IPX_K_TRACEBACK, 17), k_tb_diag<32>, ws.tbd_waves, 64, ipx_tbd_lds_bytes(32), b, (const uint32_t *)l32, (const uint32_t *)(c16 + 1), l64, c16 + 2, ws.tb_esc, ws.tb_esc_n);
+                be.launch(IPX_KEY(IPX_K_TRACEBACK, 18), k_tb_diag<64>, ws.tbd_waves, 64, ipx_tbd_lds_bytes(64), b, (const uint32_t *)l64, (const uint32_t *)(c16 + 2), ws.tb_esc, ws.tb_esc_n, ws.tb_esc, ws.tb_esc_n);
+            }
             // everything else: one wavefront per job
             be.launch(IPX_KEY(IPX_K_TRACEBACK, 1), k_tb_coop, ws.tb1_waves, 64, ipx_tbc_lds_bytes(ws.tb1.arrcap_lds), b,
                       (const uint32_t *)ws.tb_esc, (const uint32_t *)ws.tb_esc_n, ws.tb1.dir, (int64_t)ws.tb1.dircap,

@@ -73,7 +73,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_esc, tb1, maxcol, tbf, long_state;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
+    DevBuf perm, tb_list, tb_esc, tb_bw, tb1, maxcol, tbf, long_state;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -254,7 +254,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_esc, &c->tb1, &c->maxcol, &c->tbf, &c->long_state})
+                      &c->tb_list, &c->tb_esc, &c->tb_bw, &c->tb1, &c->maxcol, &c->tbf, &c->long_state})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -333,8 +333,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
         c->ref_len.ensure(4 * ((size_t)n_refs + 1)) || c->ref_id.ensure(4 * (size_t)n_jobs + 4) ||
         c->gap_open.ensure((size_t)n_jobs + 4) || c->gap_ext.ensure((size_t)n_jobs + 4) ||
         (mask_len && c->mask_len.ensure(4 * (size_t)n_jobs + 4)) || c->res.ensure(32 * (size_t)n_jobs + 32) ||
-        c->perm.ensure(12 * (size_t)n_jobs + 16) || c->tb_list.ensure(28 * (size_t)n_jobs + 32) ||
-        c->tb_esc.ensure(4 * (size_t)n_jobs + 4) ||
+        c->perm.ensure(12 * (size_t)n_jobs + 16) || c->tb_list.ensure(4 * (size_t)IPX_TB_NLISTS * (size_t)n_jobs + 32) ||
+        c->tb_esc.ensure(4 * (size_t)n_jobs + 4) || c->tb_bw.ensure(2 * (size_t)n_jobs + 4) ||
         c->small.ensure(4 * ((size_t)IPX_PLAN_TABLE_WORDS + (size_t)IPX_NUM_PASSES * 3 * (IPX_NUM_CLASSES + 1) + IPX_NUM_CLASSES + 64 + (IPX_NUM_PASSES * IPX_NUM_CLASSES + 3) / 4)))
         return IPX_ERR_NO_DEVICE;
     if (c->cigar_cap < (uint32_t)(n_jobs * 8 + 1024)) c->cigar_cap = (uint32_t)(n_jobs * 8 + 1024);
@@ -429,8 +429,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     }
     c->ws.tb_list = c->tb_list.as<uint32_t>();
     c->ws.tb_esc = c->tb_esc.as<uint32_t>();
-    c->ws.tb_list_n = sm; sm += 8;
-    c->ws.tb_esc_n = c->ws.tb_list_n + 7;
+    c->ws.tb_list_n = sm; sm += IPX_TB_NCOUNTERS;
+    c->ws.tb_esc_n = c->ws.tb_list_n + IPX_TB_CLS_COOP;
     uint32_t *cursor = sm; sm += 4;
     uint32_t *status = sm; sm += 4;
     c->cls_map_dev = (uint8_t *)sm; sm += (IPX_NUM_PASSES * IPX_NUM_CLASSES + 3) / 4;
@@ -449,6 +449,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     b.cigar_cursor = cursor; b.status = status;
     b.plan_counts = c->ws.plan_tables;
     b.maxcol_scratch = c->maxcol.as<uint32_t>();
+    b.tb_bw = c->tb_bw.as<uint16_t>();
+    c->ws.tbd_waves = c->num_cu * 8;                         // k_tb_diag: 21 KB of LDS per one-wave block, seven resident per CU
     if (!c->async_io) HIPCHK(hipStreamSynchronize(s));
     c->n_jobs = n_jobs; c->n_refs = n_refs;
     return IPX_OK;
@@ -467,6 +469,7 @@ int ipx_run(ipx_ctx *c)
     b.byte_safe_len = ipx_byte_safe_len(c->mat, c->bias);
     { int mx = 0; for (int k = 0; k < 25; ++k) if (c->mat[k] > mx) mx = c->mat[k]; b.max_match = mx; }
     b.exact_direct = ipx_perm_profile_ok(c->mat, c->routing) && !(c->routing & IPX_ROUTE_NO_EXACT_DIRECT);   // (the stepped selector-profile kernels: cheap where no cut can happen)
+    b.tb_diag = !(c->routing & IPX_ROUTE_TB_NO_DIAG);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
@@ -645,7 +648,7 @@ const char *ipx_kernel_class_name(int k)
         else if (sub >= IPX_SUB_TIER) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub - IPX_SUB_TIER);
         else if (sub >= IPX_SLOW_BASE) snprintf(buf, sizeof buf, "%s_slowgap_s%d", k_names[kc], sub - IPX_SLOW_BASE);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
-    } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub == 10) snprintf(buf, sizeof buf, "%s_fast_bw4to7", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
+    } else if (kc == IPX_K_TRACEBACK) { if (sub == 9) snprintf(buf, sizeof buf, "%s_fast_all", k_names[kc]); else if (sub == 10) snprintf(buf, sizeof buf, "%s_fast_bw4to7", k_names[kc]); else if (sub >= 16 && sub <= 18) snprintf(buf, sizeof buf, "%s_diag%d", k_names[kc], 16 << (sub - 16)); else if (sub == 1) snprintf(buf, sizeof buf, "%s_coop", k_names[kc]); else if (sub >= 2) snprintf(buf, sizeof buf, "%s_fast_bw%d", k_names[kc], sub - 1); else snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub); }
     else snprintf(buf, sizeof buf, "%s", k_names[kc]);
     return buf;
 }
@@ -669,8 +672,8 @@ int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out)
 {
     if (!c || !out || !c->ws.tb_list_n) return IPX_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy(out, c->ws.tb_list_n, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    out[8] = 0;
+    HIPCHK(hipMemcpy(out, c->ws.tb_list_n, 11 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out[11] = 0;
     return IPX_OK;
 }
 

@@ -88,6 +88,7 @@ enum {
                                       //   the stepped pass at once (which steps only where a cut can happen and costs little more than the lower bound)
     IPX_ROUTE_TB_NO_WAVE_PER_JOB = 4096,  // small batches too take the lane-per-job traceback kernels (default: up to 2048 jobs, one wave per job)
     IPX_ROUTE_TB_NO_UNGAPPED = 8192,      // every CIGAR through banded_sw's DP (default: an alignment whose diagonal alone reaches score1 gets its one-run CIGAR from k_tb_list)
+    IPX_ROUTE_TB_NO_DIAG = 16384,         // no anti-diagonal traceback tiers (k_tb_diag): bands wider than 7, doubled bands and small batches take one wave per job (k_tb_coop) as in r03
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 
@@ -140,6 +141,9 @@ struct IpxBatch {
                                 //   scatter cursors follow its counts); the rows of the dynamic passes are zeroed at the start of a
                                 //   run and filled by the kernels that decide a job's next pass
     uint32_t *maxcol_scratch;   // per DP block: column maxima of the tile in flight (forward passes)
+    uint16_t *tb_bw;            // n_jobs: band half-width a later traceback tier starts the job from (0: its own first band, ssw.c:899), written by the
+                                //   tier that hands the job over (k_tb_list zeroes it); only with tb_diag
+    uint8_t tb_diag;            // the anti-diagonal traceback tiers (k_tb_diag) are in use: speed only
     uint32_t *status;           // bit0: cigar pool exhausted, bit1: read too long, bit2: ref too long, bit3: traceback scratch exhausted
 };
 

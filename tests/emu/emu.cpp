@@ -263,11 +263,14 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     }
     // plan_counts[pass][class]: the count rows of plan_tables have a stride of 2 * IPX_NUM_CLASSES
     b.plan_counts = ws.plan_tables;
-    ws.tb_list = zalloc<uint32_t>(7 * (size_t)n_jobs);
+    ws.tb_list = zalloc<uint32_t>(IPX_TB_NLISTS * (size_t)n_jobs);
     ws.tb_esc = zalloc<uint32_t>((size_t)n_jobs);
     ws.tb_esc_n = nullptr;
-    ws.tb_list_n = zalloc<uint32_t>(8);
-    ws.tb_esc_n = ws.tb_list_n + 7;
+    ws.tb_list_n = zalloc<uint32_t>(IPX_TB_NCOUNTERS);
+    ws.tb_esc_n = ws.tb_list_n + IPX_TB_CLS_COOP;
+    b.tb_bw = zalloc<uint16_t>((size_t)n_jobs);
+    b.tb_diag = !(routing & IPX_ROUTE_TB_NO_DIAG);
+    ws.tbd_waves = 2;
     const IpxTbSizing s1 = ipx_tb1_sizing(d);
     ws.tbf_waves = 7;
     ws.tbf_scratch = (unsigned char *)malloc(ipx_tbf_scratch_bytes_per_block(IPX_TBF_ROWCAP) * 7 + 64);
@@ -298,10 +301,12 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
             pass_jobs_out[ps] = 0;
             for (int c = 0; c < IPX_NUM_CLASSES; ++c) pass_jobs_out[ps] += ipx_plan_count_of(ws.plan_tables, ps)[c];
         }
+    if (pass_jobs_out)                                           // jobs pushed to k_tb_coop's list and to the three anti-diagonal tiers' lists
+        for (int q = 0; q < 4; ++q) pass_jobs_out[11 + q] = ws.tb_list_n[IPX_TB_CLS_COOP + q];
     free(packed);
     free(b.maxcol_scratch);
     free(ws.plan_tables); free(ws.exact_starters); free(offs); free(perms);
-    free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n);
+    free(ws.tb_list); free(ws.tb_esc); free(ws.tb_list_n); free(b.tb_bw);
     free(ws.tb1.dir); free(ws.tb1.cig); free(ws.tb1.band); free(ws.tbf_scratch); free(ws.long_state);
     free(dp);
     return 0;

@@ -75,6 +75,7 @@ class EmuAligner:
         self.status = st.value
         self.launches = {int(k): int(launches[k]) for k in np.flatnonzero(launches)}
         self.pass_jobs = pass_jobs[:10].tolist()    # jobs per pass (IPX_PASS_* order of csrc/ipx_types.h)
+        self.tb_jobs = pass_jobs[11:15].tolist()    # jobs listed for k_tb_coop and for k_tb_diag<16 / 32 / 64> (hand-overs included)
         used = int((rec["cigar_off"].astype(np.int64) + rec["cigar_len"]).max()) if n else 0
         return BatchResult(rec, pool[:used])
 

@@ -448,3 +448,66 @@ def test_emu_long_reads_take_the_long_read_kernel(emu, oracle_mod, port):
         assert a.status == 0
         _compare(res, [(r, w, o_, e_) for r, o_, e_ in zip(reads, go, ge)], port, oracle_mod.dna_matrix(ms, mm))
         assert any(k % 256 == 141 for k in a.launches)                    # IPX_SUB_LONG: the long-read kernel ran
+
+
+def test_emu_anti_diagonal_traceback_tiers(emu, oracle_mod, port):
+    """r04, k_tb_diag<16 / 32 / 64>: banded_sw as an anti-diagonal wavefront.  Jobs whose first band |refLen - readLen| + 1 runs from 1 to
+    ~90 (deletions and insertions of 1..90 bp bridged under cheap gap extension), compensating indels that make a band double inside
+    a tier and across tiers, windows narrower than the band arrays (the reference's `h_b[edge] = 0` wipes a cell inside the band there),
+    reads with N, short rectangles; every field and CIGAR against the oracle -- as a small batch (every job takes a tier), behind the
+    lane-per-job kernels (large-batch routing), and with the tiers switched off."""
+    rng = np.random.default_rng(404)
+    w = rng.integers(0, 4, 520).astype(np.int8)
+    w2 = rng.integers(0, 2, 90).astype(np.int8)                     # low complexity: ties, wandering paths
+    reads, rid, go, ge = [], [], [], []
+    gaps = [(3, 0), (1, 0), (3, 1), (2, 1), (5, 0), (4, 1), (1, 1), (0, 0)]
+    for i in range(72):
+        st = int(rng.integers(0, 200))
+        L = int(rng.integers(60, 200))
+        r = w[st:st + L].copy()
+        kind = i % 6
+        d = (1, 3, 9, 14, 17, 30, 33, 47, 62, 70, 90, 5, 22, 12)[(i // 6 + 5 * (i % 6)) % 14]
+        if kind in (0, 1):                                         # deletion of d bp: first band d + 1
+            cut = int(rng.integers(20, L - 20))
+            r = np.concatenate([w[st:st + cut], w[st + cut + d:st + L + d]])
+        elif kind == 2:                                            # insertion of d bp
+            cut = int(rng.integers(20, L - 20))
+            r = np.concatenate([r[:cut], rng.integers(0, 4, min(d, 60)).astype(np.int8), r[cut:]])
+        elif kind == 3:                                            # insertion of k, deletion of k further on: the band doubles
+            k = 1 + i % 11
+            a, b2 = 25, L - 30
+            r = np.concatenate([r[:a], rng.integers(0, 4, k).astype(np.int8), r[a:b2], r[b2 + k:]])
+        elif kind == 4:
+            r[rng.integers(0, len(r), 4)] = 4
+        if i % 9 == 0:
+            r = r[:int(rng.integers(3, 12))]                         # rectangles of a few cells
+        g = gaps[i % len(gaps)]
+        reads.append(r); rid.append(0); go.append(g[0]); ge.append(g[1])
+    for i in range(16):                                            # low-complexity window, 2-letter reads
+        st = int(rng.integers(0, 30))
+        r = w2[st:st + int(rng.integers(8, 55))].copy()
+        if i % 2:
+            r = np.concatenate([r[:5], r[5 + i % 7:]])
+        g = gaps[(i + 3) % len(gaps)]
+        reads.append(r); rid.append(1); go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, [w, w2], rid, go, ge, encoded=True)
+    mat = oracle_mod.dna_matrix(3, 2)
+    refs = [w, w2]
+    exp = [port.align(r, refs[rid[i]], mat, go[i], ge[i]) for i, r in enumerate(reads)]
+    first_bands = [abs((e["ref_end1"] - e["ref_begin1"]) - (e["read_end1"] - e["read_begin1"])) + 1 for e in exp if e["cigar"]]
+    assert sum(1 for f in first_bands if 8 <= f <= 15) >= 3 and sum(1 for f in first_bands if 16 <= f <= 31) >= 3
+    assert sum(1 for f in first_bands if 32 <= f <= 63) >= 3 and sum(1 for f in first_bands if f >= 64) >= 2
+    seen = {}
+    for routing in (0, R.ROUTE_TB_NO_WAVE_PER_JOB, R.ROUTE_TB_NO_WAVE_PER_JOB | R.ROUTE_TB_NO_FUSE, R.ROUTE_TB_NO_DIAG, R.ROUTE_TB_NO_UNGAPPED):
+        a = emu(0, 3, 2)
+        a.set_routing(routing)
+        res = a.align(jobs)
+        assert a.status == 0
+        for i in range(len(reads)):
+            assert res.as_dict(i) == exp[i], (routing, i, res.as_dict(i), exp[i])
+        seen[routing] = a.tb_jobs
+    coop, d16, d32, d64 = seen[0]
+    assert d16 >= 40 and d32 >= 8 and d64 >= 4 and 2 <= coop <= 12, seen      # small batch: every job starts in a tier; only bands past 63 reach k_tb_coop
+    assert d32 > sum(1 for f in first_bands if 16 <= f <= 31) or d64 > sum(1 for f in first_bands if 32 <= f <= 63), (seen, first_bands)   # some reach a tier by doubling out of the one below
+    assert seen[R.ROUTE_TB_NO_WAVE_PER_JOB][1] < d16                           # behind the lane-per-job kernels the first tier sees wide and doubled bands only
+    assert seen[R.ROUTE_TB_NO_DIAG][1:] == [0, 0, 0]
