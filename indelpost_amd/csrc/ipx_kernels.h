@@ -58,7 +58,9 @@ template <int W> IPX_DEV pk16 group_or(pk16 x)
     x |= xl_xor1(x);
     x |= xl_xor2(x);
     x |= xl_half_mirror(x);
-    if (W == 16) x |= xl_mirror(x);
+    if (W >= 16) x |= xl_mirror(x);
+    if (W >= 32) x |= xl_shfl(x, lane_id() ^ 16);      // (32 / 64 lanes per group: the latency tier of k_dp_skew; once per group of steps at most)
+    if (W >= 64) x |= xl_shfl(x, lane_id() ^ 32);
     return x;
 }
 template <int W> IPX_DEV pk16 group_max(pk16 x)
@@ -66,7 +68,9 @@ template <int W> IPX_DEV pk16 group_max(pk16 x)
     x = pk_max(x, xl_xor1(x));
     x = pk_max(x, xl_xor2(x));
     x = pk_max(x, xl_half_mirror(x));
-    if (W == 16) x = pk_max(x, xl_mirror(x));
+    if (W >= 16) x = pk_max(x, xl_mirror(x));
+    if (W >= 32) x = pk_max(x, xl_shfl(x, lane_id() ^ 16));
+    if (W >= 64) x = pk_max(x, xl_shfl(x, lane_id() ^ 32));
     return x;
 }
 template <int W> IPX_DEV uint32_t group_umax(uint32_t x)
@@ -75,7 +79,9 @@ template <int W> IPX_DEV uint32_t group_umax(uint32_t x)
     y = xl_xor1(x); x = x > y ? x : y;
     y = xl_xor2(x); x = x > y ? x : y;
     y = xl_half_mirror(x); x = x > y ? x : y;
-    if (W == 16) { y = xl_mirror(x); x = x > y ? x : y; }
+    if (W >= 16) { y = xl_mirror(x); x = x > y ? x : y; }
+    if (W >= 32) { y = xl_shfl(x, lane_id() ^ 16); x = x > y ? x : y; }
+    if (W >= 64) { y = xl_shfl(x, lane_id() ^ 32); x = x > y ? x : y; }
     return x;
 }
 template <int W> IPX_DEV uint32_t group_umin(uint32_t x)
@@ -84,7 +90,9 @@ template <int W> IPX_DEV uint32_t group_umin(uint32_t x)
     y = xl_xor1(x); x = x < y ? x : y;
     y = xl_xor2(x); x = x < y ? x : y;
     y = xl_half_mirror(x); x = x < y ? x : y;
-    if (W == 16) { y = xl_mirror(x); x = x < y ? x : y; }
+    if (W >= 16) { y = xl_mirror(x); x = x < y ? x : y; }
+    if (W >= 32) { y = xl_shfl(x, lane_id() ^ 16); x = x < y ? x : y; }
+    if (W >= 64) { y = xl_shfl(x, lane_id() ^ 32); x = x < y ? x : y; }
     return x;
 }
 IPX_DEV uint32_t wave_umax(uint32_t x)
@@ -1336,7 +1344,9 @@ template <int W> IPX_DEV pk16 group_minu(pk16 x)
     x = pk_minu(x, xl_xor1(x));
     x = pk_minu(x, xl_xor2(x));
     x = pk_minu(x, xl_half_mirror(x));
-    if (W == 16) x = pk_minu(x, xl_mirror(x));
+    if (W >= 16) x = pk_minu(x, xl_mirror(x));
+    if (W >= 32) x = pk_minu(x, xl_shfl(x, lane_id() ^ 16));
+    if (W >= 64) x = pk_minu(x, xl_shfl(x, lane_id() ^ 32));
     return x;
 }
 //   BH = 1: the 8-bit forward pass's UPPER-BOUND stage (k_dp_pass HIGH) for reads of up to 8*SMAX bp: what that stage computes --
@@ -1361,13 +1371,17 @@ template <int W> IPX_DEV pk16 group_minu(pk16 x)
 // than the third wave brings (r02: config 4's 200 bp class); longer reads run at two waves
 IPX_HD constexpr int ipx_skew_waves(int smax, bool rev) { return (smax >= 20 && smax <= 25) ? 3 : (rev ? ipx_dp_perm_waves(smax) : 1); }
 // one tile of k_dp_skew: the 16 reads p.perm[first .. first + cnt)
-template <int SMAX, bool REV, int BH>
+// lane l <- lane l-1: inside the 16-lane DPP row for 8 lanes per read (what crosses into a group's first lane is masked by the caller),
+// across the whole wavefront for the latency tier's 32 / 64 lanes per read
+template <int W> IPX_DEV uint32_t skew_shr1(uint32_t v) { return W <= 16 ? xl_row_shr1(v) : xl_wave_shr1(v); }
+template <int SMAX, bool REV, int BH, int W = 8>
 IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
                           unsigned char *lds, const uint32_t nz)
 {
     static_assert(!(BH == 1 && REV), "the upper-bound stage of the bracket is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
-    constexpr int W = 8, G = 8, S = SMAX;
+    static_assert(W == 8 || W == 32 || W == 64, "8 lanes per read (16 reads per wave), or the latency tier's 32 / 64");
+    constexpr int G = 64 / W, S = SMAX;
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
     // ---- per-slot parameters (index 0 = low half, 1 = high half of every packed register) ----
@@ -1407,7 +1421,7 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
     // rows the read is shifted down by: the kernel's row count minus the reference's padded row count for this read (ROW SHIFT above)
     int dl[2];
     IPX_UNROLL
-    for (int h = 0; h < 2; ++h) dl[h] = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
+    for (int h = 0; h < 2; ++h) dl[h] = W * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
     {   // this kernel has no stepped lazy-F and computes in halves: refuse what would need more (host-side routing error)
         const bool bad = (job[0] >= 0 && (gO[0] <= gE[0] || L[0] > b.f16_max_len || dl[0] < 0)) ||
                          (job[1] >= 0 && (gO[1] <= gE[1] || L[1] > b.f16_max_len || dl[1] < 0));
@@ -1516,25 +1530,25 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
         // the DP, so the two LDS reads of step u + 1 are issued before the stripe of step u and have arrived when it is done.
         // -- the first lane's column is t; lane l takes over lane l-1's letters of the step before
         // (one v_perm_b32 with a per-lane selector: the first lane picks its two bytes of the pair, the others the lane above's letters)
-        let = pk_perm(xl_row_shr1(let), pairA, lsel0);
+        let = pk_perm(skew_shr1<W>(let), pairA, lsel0);
         uint32_t tabn0 = *(const uint32_t *)(lds + (let & 0xFFu)), tabn1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
         IPX_UNROLL
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u;
             const uint32_t tab0 = tabn0, tab1 = tabn1;
             if (u < 3) {
-                let = pk_perm(xl_row_shr1(let), ((u + 1) & 2) ? pairB : pairA, ((u + 1) & 1) ? lsel1 : lsel0);
+                let = pk_perm(skew_shr1<W>(let), ((u + 1) & 2) ? pairB : pairA, ((u + 1) & 1) ? lsel1 : lsel0);
                 tabn0 = *(const uint32_t *)(lds + (let & 0xFFu));
                 tabn1 = *(const uint32_t *)(lds + ((let >> 8) & 0xFFu));
             }
             // -- what the lane above passes on: the diagonal H (two steps old), F and the column maximum so far (one step old)
-            const pk16 vH = xl_row_shr1(Hl_old) & nz;
-            pk16 vF = xl_row_shr1(vFend) & nz;
+            const pk16 vH = skew_shr1<W>(Hl_old) & nz;
+            pk16 vF = skew_shr1<W>(vFend) & nz;
             // The column maximum starts from what the lanes above found in this column, so that after the stripe it is the
             // maximum over the lanes up to this one.  The lane's best below therefore also covers the rows ABOVE its own in the
             // columns it has processed: harmless -- the lane that owns such a row records the same value at the same column, so
             // neither the best, nor its first column, nor (smallest row wins) the row found in the snapshots changes.
-            pk16 cmx = xl_row_shr1(pm) & nz;
+            pk16 cmx = skew_shr1<W>(pm) & nz;
             dp_stripe_f16<SMAX>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
             vFend = vF;
             Hl_old = Hl_cur;
@@ -1616,7 +1630,7 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
         // first row (ROW SHIFT: the rows above it hold 0, which is the best only when nothing scored -- row 0 then, as in the reference)
         const unsigned bh = (bestA >> (16 * h)) & 0xFFFFu;
         const bool mine = ((isc >> (16 * h)) & 0xFFFFu) != 0;
-        const int shift = 8 * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
+        const int shift = W * S - (BH ? 16 * ((L[h] + 15) >> 4) : 8 * ((L[h] + 7) >> 3));
         uint32_t rmin = 0x7FFFFFFFu;
         IPX_UNROLL
         for (int j = SMAX - 1; j >= 0; --j)
@@ -1720,7 +1734,7 @@ IPX_DEV void dp_skew_tile_at(int c, const IpxBatch &b, const IpxPlan &p, uint32_
 // prologue shared by the wavefront kernels: the score table in LDS (offset 0: [6 window letters][4 read letters], the high byte of each score
 // as a half, looked up by byte offset = letter x 4), this block's column maxima, the lane-0 mask
 #define IPX_SKEW_PROLOGUE                                                                                                             \
-    constexpr int W = 8, G = 8, NA = 16;                                                                                              \
+    constexpr int G = 64 / W, NA = 2 * G;                                                                                             \
     const int lane = lane_id();                                                                                                       \
     const int l = lane % W;                                                                                                           \
     unsigned char *lds = IPX_LDS_BASE;                                                                                                \
@@ -1735,15 +1749,23 @@ IPX_DEV void dp_skew_tile_at(int c, const IpxBatch &b, const IpxPlan &p, uint32_
     uint32_t nz = l == 0 ? 0u : 0xFFFFFFFFu;       /* what arrives from the lane above: nothing, in the first lane */                 \
     IPX_KEEP_VGPR(nz);                             /* (kept a register: v_and_b32 costs 2 cycles, the v_cndmask_b32 on a lane mask the compiler prefers 4) */
 
-template <int SMAX, bool REV, int BH = 0>
-IPX_KERNEL_WAVE_OCC(ipx_skew_waves(SMAX, REV)) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
+// W (r04): lanes per read.  8 = the throughput form (16 reads per wave, 8 * SMAX rows).  32 = the LATENCY TIER for small batches (up to
+// IPX_LAT_MAX_JOBS jobs: one locus of indelPost is a few hundred to two thousand alignments, varaln.pyx:112, localn.pyx:47-66): the chip has
+// more SIMDs than such a batch has 16-read tiles, so a pass lasts as long as ONE wave needs for its tile -- columns x instructions per step.
+// With 32 lanes per read a lane holds a quarter of the segments (32 * SMAX rows, SMAX = ceil(rows / 32)): a step is ~9.5 * SMAX + 22
+// instructions instead of ~9.5 * 4 * SMAX + 22, for 31 instead of 7 steps of wavefront lead-in: 150 bp against 300 bp, 332 x 70 instead of
+// 307 x 205 instructions per tile.  Four reads per wave; the lane-to-lane hand-over is a whole-wavefront DPP shift (wave_shr:1) instead
+// of a row shift; the per-read reductions of the finalisation add two ds_bpermute steps.  Same recurrence, same outputs (ROW SHIFT serves
+// any read whose padded row count fits).
+template <int SMAX, bool REV, int BH = 0, int W = 8>
+IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
 {
     IPX_SKEW_PROLOGUE
     for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
         if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
         const uint32_t first = p.cls_off[cls] + want * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;
-        dp_skew_tile<SMAX, REV, BH>(b, p, first, avail < (uint32_t)NA ? (int)avail : NA, pass, maxcol, mc_lds, lds, nz);
+        dp_skew_tile<SMAX, REV, BH, W>(b, p, first, avail < (uint32_t)NA ? (int)avail : NA, pass, maxcol, mc_lds, lds, nz);
     }
 }
 
@@ -1760,6 +1782,7 @@ IPX_KERNEL_WAVE_OCC(ipx_tier_waves(SHI)) void k_dp_skew_tier(IpxBatch b, IpxPlan
 {
     constexpr int STEP = BH ? 2 : 1, C0 = SLO / STEP, C1 = SHI / STEP;             // classes of the tier
     static_assert(SLO % STEP == 0 && SHI % STEP == 0 && C1 - C0 < 32, "tier bounds");
+    constexpr int W = 8;
     IPX_SKEW_PROLOGUE
     int own_cls = C0;                                                 // class reached by the walk
     uint32_t own_base = 0;                                            // owned tiles in the classes before own_cls
@@ -2542,8 +2565,12 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                     const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
                     if (b.tb_diag) {
                         b.tb_bw[i] = 0;                                                        // (every tier starts the job from its own first band)
+                        // (a small batch starts in a WIDER tier than its band needs: more lanes per job = more widths of the doubling sequence
+                        //  side by side -- all_general 1: at least 32 lanes per job, 2: 64)
+                        const int lo = all_general >= 2 ? 63 : all_general == 1 ? 31 : 15;
+                        const int bt = bw > lo ? bw : lo;
                         const int tier = (readLen > IPX_TBD_ROWS || readLen < 1 || refLen < 1) ? IPX_TB_CLS_COOP
-                                         : bw <= 15 ? IPX_TB_CLS_DIAG : bw <= 31 ? IPX_TB_CLS_DIAG + 1 : bw <= 63 ? IPX_TB_CLS_DIAG + 2 : IPX_TB_CLS_COOP;
+                                         : bt <= 15 ? IPX_TB_CLS_DIAG : bt <= 31 ? IPX_TB_CLS_DIAG + 1 : bt <= 63 ? IPX_TB_CLS_DIAG + 2 : IPX_TB_CLS_COOP;
                         cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : tier;
                     } else cls[k] = (bw <= IPX_TBF_MAXBW && !all_general) ? bw - 1 : IPX_TB_CLS_COOP;   // (all_general: a small batch, one wave per job)
                     if (ungapped && exact_opt && bw == 1 && readLen > 0 && r.ref_begin1 >= 0 && r.read_begin1 >= 0 && tb_ungapped(b, r, i, readLen, coltab)) {
@@ -3090,42 +3117,40 @@ IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t 
 // The tiers between the lane-per-job kernels (first band <= 7, no help for a small batch: one lane walks a whole job) and the
 // wave-per-job kernel (k_tb_coop: three barriers and a scan over 64 lanes per DP row, whatever the band): bands of half-width
 // 8..15 / ..31 / ..63, and EVERY job of a small batch.
-//   Lane k of a job's group owns the band diagonals q = 2k and 2k+1 (q = j - i + bw, 0..2bw: up to LG - 1 = bw).  A cell (i, q) sits on
-//   anti-diagonal tau = 2i + q; at step tau lane k works on row i = tau / 2 - k of diagonal 2k + (tau & 1).  Everything a cell needs is
+//   A band of half-width bw takes bw + 1 lanes: lane k owns the band diagonals q = 2k and 2k+1 (q = j - i + bw, 0..2bw).  A cell (i, q) sits
+//   on anti-diagonal tau = 2i + q; at step tau lane k works on row i = tau / 2 - k of diagonal 2k + (tau & 1).  Everything a cell needs is
 //   one or two steps old: the upper neighbour (i-1, q+1) and the left one (i, q-1) are on anti-diagonal tau - 1 -- in the lane's own
 //   other diagonal, or in the neighbouring lane's (one DPP shift) -- the diagonal one (i-1, q) on tau - 2 in the lane's own registers.
 //   So a step is straight-line code without any scan, barrier or memory dependency: 2 * rows + 2 * bw steps for a band, H / E / F of
 //   the last two anti-diagonals in six registers per lane.
-//   Out-of-band and out-of-rectangle neighbours read 0, as the reference's h_b / e_b / h_c arrays do (ssw.c:627, 633) -- with the
-//   reference's one irregularity kept: `h_b[edge] = e_b[edge] = 0` (ssw.c:632-633) wipes the upper neighbour of the LAST window column in
-//   rows 1..bw+1 when the window is no wider than the band arrays (refLen <= 2bw + 2) although that neighbour is inside the band.  (The
-//   formulation "cell by cell with these neighbour rules" was checked against a literal transcription of the reference's loops on 40 000
-//   random rectangles before the kernel was written.)
+//   SEVERAL BAND WIDTHS AT ONCE.  The reference doubles the band until the banded maximum reaches the score (ssw.c:668-669), and a narrow
+//   band has nothing to run in parallel but its bw + 1 anti-diagonal cells: run one after the other, the iterations bw, 2bw, 4bw.. are a
+//   chain of 2 * rows dependent steps EACH.  The lanes a narrow band leaves idle take the next widths of the doubling sequence in the same
+//   steps -- bands 1, 2, 4 are 2 + 3 + 5 lanes of a 16-lane group; 1, 2, 4, 8 are 19 of 32; 1..16 are 36 of 64 -- each sub-band with its
+//   own lanes, registers and direction words; afterwards the first width whose maximum reaches the score (or that is the sequence's last,
+//   2bw > len) is the reference's final iteration and its directions are walked.  Widths nobody needed cost nothing but idle lanes' work.
+//   Out-of-band and out-of-rectangle neighbours read 0, as the reference's h_b / e_b / h_c arrays do (ssw.c:627, 633) -- which also gives
+//   row 0 its -gapO / -gapE seeds (ssw.c:644-645) -- with the reference's one irregularity kept: `h_b[edge] = e_b[edge] = 0` (ssw.c:632-633)
+//   wipes the upper neighbour of the LAST window column in rows 1..bw+1 when the window is no wider than the band arrays (refLen <= 2bw + 2)
+//   although that neighbour is inside the band.  (The formulation "cell by cell with these neighbour rules" was checked against a literal
+//   transcription of the reference's loops on 40 000 random rectangles before the kernel was written.)
 //   Directions: one nibble per cell (k_tb_fast's code: 0 = never written, else 1 + 4 * Hsrc + 2 * Fopen + Eopen), eight steps = four rows
-//   x two diagonals per 32-bit word, words in LDS [hi / 4][lane] with hi = row + lane: the walk back (lane 0 of the group, ssw.c:673-751)
-//   finds cell (row, slot) -- the reference's linear cell index, so out-of-band reads alias as there -- at lane q / 2, word (row + lane) / 4.
-//   Only the LAST band iteration's cells exist here: a walk that meets an unwritten cell after an earlier, narrower iteration (in this
-//   kernel or a previous tier) hands the job to k_tb_coop, which keeps the reference's one buffer across iterations; without an earlier
+//   x two diagonals per 32-bit word, words in LDS [hi / 4][lane] with hi = row + lane-in-band: the walk back (first lane of the group,
+//   ssw.c:673-751) finds cell (row, slot) -- the reference's linear cell index, so out-of-band reads alias as there -- at lane q / 2 of the
+//   band, word (row + q / 2) / 4.
+//   Only the FINAL iteration's cells exist here: a walk that meets an unwritten cell after an earlier, narrower iteration (in this kernel
+//   or a previous tier) hands the job to k_tb_coop, which keeps the reference's one buffer across iterations; without an earlier
 //   iteration an unwritten cell is the reference's "Trace back error" (flag 1), as everywhere.
-//   A band that outgrows the tier (max < score, ssw.c:669, and 2bw > LG - 1) is handed to the next tier with the band to start from
+//   A band that outgrows the tier (max < score and the next width > LG - 1) is handed to the next tier with the band to start from
 //   (IpxBatch::tb_bw): the narrower iterations' only lasting effect is the stale cells the previous paragraph deals with.
-// Dynamic LDS: 64 B score table | per group: read letters IPX_TBD_ROWS | window letters IPX_TBD_ROWS + LG | direction words | IPX_TBD_CIG runs
+// Dynamic LDS: 64 B score table | per group: row score words 8 * IPX_TBD_ROWS | window letters IPX_TBD_ROWS + LG | direction words | IPX_TBD_CIG runs
 // ------------------------------------------------------------------------------------------------
-IPX_HD constexpr int ipx_tbd_group_bytes(int lg) { return IPX_TBD_ROWS + (IPX_TBD_ROWS + lg) + ((IPX_TBD_ROWS + lg) / 4) * lg * 4 + IPX_TBD_CIG * 4; }
+IPX_HD constexpr int ipx_tbd_group_bytes(int lg) { return 8 * IPX_TBD_ROWS + (IPX_TBD_ROWS + lg) + ((IPX_TBD_ROWS + lg) / 4) * lg * 4 + IPX_TBD_CIG * 4; }
 IPX_HD constexpr int ipx_tbd_lds_bytes(int lg) { return 64 + (64 / lg) * ipx_tbd_group_bytes(lg); }
+#define IPX_TBD_MAXSUB 5          // band widths run side by side at most (1, 2, 4, 8, 16 in 36 of 64 lanes)
 
-template <int LG> IPX_DEV uint32_t tbd_from_lower(uint32_t v, int k)      // lane k <- lane k-1 of the group, first lane <- 0
-{
-    if (LG == 16) return xl_row_shr1(v);
-    const uint32_t y = xl_wave_shr1(v);
-    return k == 0 ? 0u : y;
-}
-template <int LG> IPX_DEV uint32_t tbd_from_upper(uint32_t v, int k)      // lane k <- lane k+1 of the group, last lane <- 0
-{
-    if (LG == 16) return xl_row_shl1(v);
-    const uint32_t y = xl_wave_shl1(v);
-    return k == LG - 1 ? 0u : y;
-}
+template <int LG> IPX_DEV uint32_t tbd_from_lower(uint32_t v) { return LG == 16 ? xl_row_shr1(v) : xl_wave_shr1(v); }      // lane k <- lane k-1
+template <int LG> IPX_DEV uint32_t tbd_from_upper(uint32_t v) { return LG == 16 ? xl_row_shl1(v) : xl_wave_shl1(v); }      // lane k <- lane k+1
 template <int LG> IPX_DEV uint32_t tbd_group_umax(uint32_t x)
 {
     if (LG == 16) return group_umax<16>(x);
@@ -3140,8 +3165,8 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
     const int lane = lane_id(), k = lane % LG, grp = lane / LG;
     unsigned char *lds = IPX_LDS_BASE;
     uint64_t *coltab = (uint64_t *)lds;                             // [read letter a] -> bytes mat[c][a], c = 0..4
-    int8_t *sread = (int8_t *)(lds + 64 + grp * GB);
-    int8_t *sref = sread + ROWS;
+    uint64_t *srow = (uint64_t *)(lds + 64 + grp * GB);             // [row] -> the row's scores against the five window letters (coltab[read letter])
+    int8_t *sref = (int8_t *)(srow + ROWS);                         // [column] -> window letter TIMES EIGHT (a shift count into the row's score word)
     uint32_t *dirw = (uint32_t *)(sref + REFCAP);                   // [hi / 4][lane of the group]
     uint32_t *cig = dirw + NW * LG;
     if (lane < 5) {
@@ -3171,97 +3196,145 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
         int bw = start ? start : (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
         // 0 = this tier's, 1 = hand over to the next tier (band too wide), 2 = k_tb_coop from its first band, 3 = no job in this group
         int route = !has ? 3 : (readLen < 1 || refLen < 1 || readLen > ROWS || refLen > REFCAP) ? 2 : 0;
-        if (route == 0) {                                             // the job's letters, staged once (codes outside 0..4 -> N, ssw.c's read is sanitised by sswpy)
-            for (int q = k; q < readLen; q += LG) { const int a = readp[q]; sread[q] = (int8_t)((unsigned)a > 4u ? 4 : a); }
-            for (int q = k; q < refLen; q += LG) { const int ri = rb + q; sref[q] = (ri >= 0 && ri < fullRef) ? refp[ri] : (int8_t)0; }
+        if (route == 0) {                                             // the job's letters, staged once (codes outside 0..4 -> N as everywhere)
+            for (int q = k; q < readLen; q += LG) { const int a = readp[q]; srow[q] = coltab[(unsigned)a > 4u ? 4 : a]; }
+            for (int q = k; q < refLen; q += LG) { const int ri = rb + q; sref[q] = (int8_t)(((ri >= 0 && ri < fullRef) ? refp[ri] : 0) * 8); }
         }
         IPX_SYNC();
 
-        bool settled = false;
-        int iters = 0;
-        for (;;) {                                                    // band iterations (ssw.c:624-669); groups that are done idle
+        int fin_bw = 0, fin_base = 0;                                 // the final iteration: its band and the first lane of its sub-band
+        bool settled = false, earlier = start != 0;                   // earlier: some narrower iteration ran before the final one
+        for (;;) {                                                    // rounds of band iterations (ssw.c:624-669); groups that are done idle
             bool run = route == 0 && !settled;
             if (run && bw > LG - 1) { route = 1; run = false; }
             if (!xl_any(run)) break;
-            const int TH = (int)xl_first(wave_umax(run ? (uint32_t)(readLen + bw) : 0u));     // hi = 0 .. readLen - 1 + bw
-            const bool quirk = refLen <= 2 * bw + 2;                  // (see above: h_b[edge] = 0 hits a cell inside the band)
+            // the widths of this round: bw, 2bw, .. while they fit into the group's lanes and the reference's loop could still reach them
+            // (an iteration of width w runs only if w <= len, ssw.c:669)
+            int nsub = 0, wlast = 0, used = 0;
+            int sbw = 0, sbase = 0, sidx = -1;                        // this lane's sub-band: width, first lane, index
+            if (run) {
+                int w = bw;
+                while (nsub < IPX_TBD_MAXSUB && used + w + 1 <= LG && (nsub == 0 || w <= len)) {
+                    if (k >= used && k <= used + w) { sbw = w; sbase = used; sidx = nsub; }
+                    used += w + 1; wlast = w; ++nsub;
+                    w *= 2;
+                }
+            }
+            const int kl = k - sbase;                                 // lane within its sub-band
+            const bool mine = sidx >= 0;
+            const int TH = (int)xl_first(wave_umax(run ? (uint32_t)(readLen + wlast) : 0u));     // hi = row + lane-in-band = 0 .. readLen - 1 + wlast
+            // rows for which this lane's two cells exist: i >= 0, i < readLen, 0 <= j < refLen with j = i + 2 kl (+1) - sbw
+            int lo0 = sbw - 2 * kl; if (lo0 < 0) lo0 = 0;
+            int hi0 = refLen + sbw - 2 * kl; if (hi0 > readLen) hi0 = readLen;
+            int lo1 = sbw - 2 * kl - 1; if (lo1 < 0) lo1 = 0;
+            int hi1 = refLen + sbw - 2 * kl - 1; if (hi1 > readLen) hi1 = readLen;
+            const uint32_t n0 = mine && hi0 > lo0 ? (uint32_t)(hi0 - lo0) : 0u;                  // even diagonal: rows lo0 .. hi0 - 1
+            const uint32_t n1 = mine && kl < sbw && hi1 > lo1 ? (uint32_t)(hi1 - lo1) : 0u;      // odd diagonal (the band's last lane has none)
+            lo0 += kl; lo1 += kl;                                     // ... as values of hi
+            // the row whose last-column upper neighbour the reference wipes (see above), as a value of hi; -1: none
+            int hq0 = -1, hq1 = -1;
+            if (mine && refLen <= 2 * sbw + 2) {
+                const int iq0 = refLen - 1 - 2 * kl + sbw, iq1 = iq0 - 1;                          // row in which the lane's even / odd cell is in the last column
+                if (iq0 >= 1 && iq0 <= sbw + 1) hq0 = iq0 + kl;
+                if (iq1 >= 1 && iq1 <= sbw + 1) hq1 = iq1 + kl;
+            }
+            const uint32_t lowmask = kl == 0 ? 0u : 0xFFFFFFFFu;      // nothing enters a band's first lane from below (the lane there is another band's)
             int He = 0, Ee = 0, Fe = 0, Ho = 0, Eo = 0, Fo = 0, mx = 0;
             uint32_t word = 0;
+            // letters one step ahead: the row's score word and the window letter of the odd cell (= the even cell's of the next row)
+            const int jbase = 2 * kl - sbw - kl;                      // j0 = hi + jbase
+            auto ref8 = [&](int j) -> int { return (j >= 0 && j < refLen) ? (int)sref[j] : 0; };
+            uint64_t mrow_n = (mine && -kl >= 0 && -kl < readLen) ? srow[-kl] : 0ull;
+            int rc0 = mine ? ref8(jbase) : 0, rc1 = mine ? ref8(jbase + 1) : 0;
             for (int hi = 0; hi < TH; ++hi) {
-                const int i = hi - k;
-                const bool rowok = run && i >= 0 && i < readLen && k <= bw;
-                const int rd = rowok ? (int)sread[i] : 0;
-                const uint64_t mrow = coltab[rd];                      // this row's scores against the five window letters
-                const int j0 = i + 2 * k - bw;
-                const bool up0 = quirk && i >= 1 && i <= bw + 1;       // rows whose last-column upper neighbour is wiped
-                // ---- even step: diagonal 2k ----
+                const uint64_t mrow = mrow_n;
+                {   // next step's letters (independent of the recurrence: the loads overlap it)
+                    const int in = hi + 1 - kl;
+                    mrow_n = (mine && in >= 0 && in < readLen) ? srow[in] : 0ull;
+                }
+                const int rcn = mine ? ref8(hi + jbase + 2) : 0;
+                // ---- even step: diagonal 2 kl ----
                 {
-                    const int Hl = (int)tbd_from_lower<LG>((uint32_t)Ho, k), Fl = (int)tbd_from_lower<LG>((uint32_t)Fo, k);
-                    const bool valid = rowok && j0 >= 0 && j0 < refLen;
-                    const int rc = valid ? (int)sref[j0] : 0;
+                    const int Hl = (int)(tbd_from_lower<LG>((uint32_t)Ho) & lowmask), Fl = (int)(tbd_from_lower<LG>((uint32_t)Fo) & lowmask);
+                    const bool valid = (uint32_t)(hi - lo0) < n0;
                     int Hu = Ho, Eu = Eo;
-                    if (up0 && j0 == refLen - 1) { Hu = 0; Eu = 0; }
-                    int t1 = i == 0 ? -gapO : Hu - gapO;                // ssw.c:644-648
-                    int t2 = i == 0 ? -gapE : Eu - gapE;
+                    if (hi == hq0) { Hu = 0; Eu = 0; }
+                    int t1 = Hu - gapO, t2 = Eu - gapE;                 // ssw.c:644-648 (row 0: the neighbours above are 0)
                     const int ev = t1 > t2 ? t1 : t2, de = t1 > t2 ? 1 : 0;
                     t1 = Hl - gapO; t2 = Fl - gapE;                     // ssw.c:650-653
-                    const int fv = t1 > t2 ? t1 : t2, df = t1 > t2 ? 1 : 0;
+                    const int fv = t1 > t2 ? t1 : t2, df = t1 > t2 ? 2 : 0;
                     const int e1 = ev > 0 ? ev : 0, f1 = fv > 0 ? fv : 0;   // ssw.c:655-664
                     t1 = e1 > f1 ? e1 : f1;
-                    t2 = He + (int)(int8_t)(mrow >> (8 * rc));
+                    t2 = He + (int)(int8_t)(mrow >> rc0);
                     const int hv = t1 > t2 ? t1 : t2;
-                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
+                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 4 : 8);
                     He = valid ? hv : 0; Ee = valid ? ev : 0; Fe = valid ? fv : 0;
-                    if (valid) { if (hv > mx) mx = hv; word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (8 * (hi & 3)); }
+                    mx = He > mx ? He : mx;
+                    word |= (valid ? (uint32_t)(1 + dh + df + de) : 0u) << (8 * (hi & 3));
                 }
-                // ---- odd step: diagonal 2k + 1 ----
+                // ---- odd step: diagonal 2 kl + 1 ----
                 {
-                    const int j1 = j0 + 1;
-                    int Hu = (int)tbd_from_upper<LG>((uint32_t)He, k), Eu = (int)tbd_from_upper<LG>((uint32_t)Ee, k);
-                    const bool valid = rowok && k < bw && j1 >= 0 && j1 < refLen;
-                    const int rc = valid ? (int)sref[j1] : 0;
-                    if (up0 && j1 == refLen - 1) { Hu = 0; Eu = 0; }
-                    int t1 = i == 0 ? -gapO : Hu - gapO;
-                    int t2 = i == 0 ? -gapE : Eu - gapE;
+                    int Hu = (int)tbd_from_upper<LG>((uint32_t)He), Eu = (int)tbd_from_upper<LG>((uint32_t)Ee);
+                    const bool valid = (uint32_t)(hi - lo1) < n1;
+                    if (hi == hq1) { Hu = 0; Eu = 0; }
+                    int t1 = Hu - gapO, t2 = Eu - gapE;
                     const int ev = t1 > t2 ? t1 : t2, de = t1 > t2 ? 1 : 0;
                     t1 = He - gapO; t2 = Fe - gapE;
-                    const int fv = t1 > t2 ? t1 : t2, df = t1 > t2 ? 1 : 0;
+                    const int fv = t1 > t2 ? t1 : t2, df = t1 > t2 ? 2 : 0;
                     const int e1 = ev > 0 ? ev : 0, f1 = fv > 0 ? fv : 0;
                     t1 = e1 > f1 ? e1 : f1;
-                    t2 = Ho + (int)(int8_t)(mrow >> (8 * rc));
+                    t2 = Ho + (int)(int8_t)(mrow >> rc1);
                     const int hv = t1 > t2 ? t1 : t2;
-                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 1 : 2);
+                    const int dh = t1 <= t2 ? 0 : (e1 > f1 ? 4 : 8);
                     Ho = valid ? hv : 0; Eo = valid ? ev : 0; Fo = valid ? fv : 0;
-                    if (valid) { if (hv > mx) mx = hv; word |= (uint32_t)(1 + dh * 4 + df * 2 + de) << (8 * (hi & 3) + 4); }
+                    mx = Ho > mx ? Ho : mx;
+                    word |= (valid ? (uint32_t)(1 + dh + df + de) : 0u) << (8 * (hi & 3) + 4);
                 }
+                rc0 = rc1; rc1 = rcn;
                 if ((hi & 3) == 3 || hi == TH - 1) { if (run) dirw[(hi >> 2) * LG + k] = word; word = 0; }
             }
-            mx = (int)tbd_group_umax<LG>((uint32_t)mx);
-            if (run) {
-                ++iters;
-                if (mx >= score || 2 * bw > len) settled = true;      // ssw.c:668-669
-                else bw *= 2;
+            // the first width of the sequence whose maximum reaches the score, or the sequence's last one (ssw.c:668-669)
+            int pick = -1;
+            {
+                int w = bw;
+                for (int m = 0; m < IPX_TBD_MAXSUB; ++m) {
+                    const int mxm = (int)tbd_group_umax<LG>(sidx == m ? (uint32_t)mx : 0u);
+                    if (run && pick < 0 && m < nsub) {
+                        if (mxm >= score || 2 * w > len) { pick = m; fin_bw = w; }
+                        else { earlier = true; w *= 2; }
+                    }
+                }
+                if (run) {
+                    if (pick >= 0) { settled = true; fin_base = 0; int ww = bw; for (int m = 0; m < pick; ++m) { fin_base += ww + 1; ww *= 2; } }
+                    else bw = w;                                      // every width of the round fell short: the next round starts at twice the last
+                }
             }
         }
         IPX_SYNC();                                                   // direction words visible to the group's first lane
 
         // ---- trace back (ssw.c:673-751): the group's first lane ----
         if (k == 0 && route == 0) {
-            const int WD = 2 * bw + 1;
-            const int nwords = (readLen + bw + 3) >> 2;               // words a lane wrote in the last iteration
+            const int fbw = fin_bw;
+            const int WD = 2 * fbw + 1;
+            const int nwords = (readLen + fbw + 3) >> 2;              // words a lane of the final band wrote
+            const uint32_t *dw = dirw + fin_base;
             int i = readLen - 1, j = refLen - 1, e = 0, lcnt = 0, plane = 2, op = 0, prev = 0;
+            int cidx = -1;                                            // the direction word held in cw (four rows of one lane: a run of matches reads LDS once in four steps)
+            uint32_t cw = 0;
             bool fail = false, full = false;
             while (i >= 0 && j > 0) {
                 // the reference's linear cell index width_d * i + (j - x): a column outside the row's band aliases into a neighbouring row
-                int row = i, slot = j - (i - bw > 0 ? i - bw : 0);
+                int row = i, slot = j - (i - fbw > 0 ? i - fbw : 0);
                 while (slot < 0) { slot += WD; --row; }
                 while (slot >= WD) { slot -= WD; ++row; }
                 int code = 0;
                 if (row >= 0 && row < readLen) {
-                    const int q = slot + (bw - row > 0 ? bw - row : 0);        // band diagonal of that slot in that row
+                    const int q = slot + (fbw - row > 0 ? fbw - row : 0);        // band diagonal of that slot in that row
                     const int lk = q >> 1, hh = row + lk;
-                    if (q <= 2 * bw && (hh >> 2) < nwords) {
-                        const int v = (int)((dirw[(hh >> 2) * LG + lk] >> (8 * (hh & 3) + 4 * (q & 1))) & 15u);
+                    if (q <= 2 * fbw && (hh >> 2) < nwords) {
+                        const int widx = (hh >> 2) * LG + lk;
+                        if (widx != cidx) { cw = dw[widx]; cidx = widx; }
+                        const int v = (int)((cw >> (8 * (hh & 3) + 4 * (q & 1))) & 15u);
                         if (v) {
                             const int de = 2 + ((v - 1) & 1), df = 4 + (((v - 1) >> 1) & 1), dh = (v - 1) >> 2;
                             code = plane == 0 ? de : plane == 1 ? df : (dh == 0 ? 1 : dh == 1 ? de : df);
@@ -3283,7 +3356,7 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
                     e = 1;
                 }
             }
-            if (full || (fail && (start != 0 || iters > 1))) route = 2;          // (stale cells of narrower iterations could matter: k_tb_coop keeps them)
+            if (full || (fail && earlier)) route = 2;                                // (stale cells of narrower iterations could matter: k_tb_coop keeps them)
             else if (fail) { r.flag = 1; r.cigar_len = 0; b.res[jb] = r; }          // ssw.c:711-719, 911
             else {
                 if (op == 0) { ++lcnt; cig[lcnt - 1] = ((uint32_t)(e + 1) << 4); }  // ssw.c:734-751
@@ -3356,6 +3429,11 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
     X(18, REV, BH) X(20, REV, BH) X(22, REV, BH) X(24, REV, BH) X(26, REV, BH) X(28, REV, BH) X(30, REV, BH) X(32, REV, BH)
 #define IPX_SKEW_BH_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_SKEW_BH_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
+// the latency tier (r04): 32 lanes per read, 1..8 segments = up to 256 rows; 16-bit passes (BH 0) and the plain recurrence in the 8-bit dialect (BH 2)
+#define IPX_LAT_FAMILY(X, REV, BH) X(1, REV, BH) X(2, REV, BH) X(3, REV, BH) X(4, REV, BH) X(5, REV, BH) X(6, REV, BH) X(7, REV, BH) X(8, REV, BH)
+#define IPX_LAT_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_LAT_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_DP_UNIT_X(X) IPX_LAT_FAMILY(X, false, 0) IPX_LAT_FAMILY(X, true, 0) IPX_LAT_FAMILY(X, false, 2) IPX_LAT_FAMILY(X, true, 2)
 // tier kernels: several classes of one occupancy in one launch
 #define IPX_TIER_SIG (IpxBatch, IpxPlan, uint32_t, int, int)
 #define IPX_TIER_WORD(X, REV) X(1, 12, REV, 0) X(13, 19, REV, 0) X(20, 25, REV, 0) X(26, 32, REV, 0)
@@ -3368,6 +3446,7 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_PASS_TIER_DEFINE(REV) template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #define IPX_PASS_TIER_EXTERN(REV) extern template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #if defined(IPX_EXTERN_KERNELS)
+IPX_DP_UNIT_X(IPX_LAT_EXTERN)
 IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
 IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 1) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 2) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, true, 2)

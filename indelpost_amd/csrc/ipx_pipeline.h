@@ -37,6 +37,7 @@ struct IpxWorkspace {
 #endif
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
 #ifndef IPX_TB_SMALL_DIAG
+#define IPX_TB_TINY_DIAG 1024    // ... up to this many: one job per wave (64 lanes: five widths of the doubling sequence side by side)
 #define IPX_TB_SMALL_DIAG 8192   // batches up to this many jobs: every traceback takes an anti-diagonal tier (4 jobs per wave at most) instead of a lane
 #endif
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
@@ -60,7 +61,14 @@ struct IpxDims {
     uint8_t high_sets;                 // (bracket flow) the upper-bound stage runs as a wavefront, launched from `set`
     int word_from;                     // 16-bit fast-gap classes below this one are planned into `set`; from it on: class-by-class launches / k_dp_long
     int plain_max_len;                 // plain-first flow: reads up to this length take the plain kernels
+    uint8_t lat;                       // latency tier (r04): a small batch whose wavefront passes run at IPX_LAT_W lanes per read, 2 * 64 / IPX_LAT_W reads per
+                                       //   tile, every class of a pass in ONE launch (ipx_plan_classes)
 };
+#ifndef IPX_LAT_MAX_JOBS
+#define IPX_LAT_MAX_JOBS 4096          // batches up to this size take the latency tier: 1 024 SIMDs x one four-read tile
+#endif
+// alignments per tile of the passes the wavefront kernels serve
+static inline int ipx_skew_na(const IpxDims &d) { return d.lat ? 2 * (64 / IPX_LAT_W) : 16; }
 
 static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
 {
@@ -272,8 +280,26 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
 // the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).  The classes of `set` that fall into one occupancy
 // tier share ONE launch (k_dp_skew_tier) when there are at least two of them; a class alone in its tier keeps its own kernel.
 template <class BE, bool REV, int BH>
-static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing)
+static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing, bool lat = false)
 {
+    if (lat && BH != 1) {
+        // latency tier: IPX_LAT_W lanes per read, the kernel with ceil(rows / IPX_LAT_W) segments serves the class (ipx_plan_classes listed every
+        // class of the pass under one)
+        const int lds = ipx_dp_lds_bytes(IPX_LAT_W, 0, REV, maxcols, true, routing);
+        const int pflag = pass | (ipx_dp_mc_in_lds(IPX_LAT_W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
+        for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
+            if (!set[c]) continue;
+            const int rows = BH ? 16 * c : 8 * c;
+            int S = (rows + IPX_LAT_W - 1) / IPX_LAT_W;
+            if (S < 1) S = 1;
+            be.note_dp(IPX_KEY(kclass, c), pass, c, 2 * (64 / IPX_LAT_W));
+            be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
+#define IPX_LAT_CASE(N) case N: if constexpr (BH != 1) be.launch(IPX_KEY(kclass, c), k_dp_skew<N, REV, BH, IPX_LAT_W>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); break;
+            switch (S) { IPX_LAT_CASE(1) IPX_LAT_CASE(2) IPX_LAT_CASE(3) IPX_LAT_CASE(4) IPX_LAT_CASE(5) IPX_LAT_CASE(6) IPX_LAT_CASE(7) IPX_LAT_CASE(8) default: break; }
+#undef IPX_LAT_CASE
+        }
+        return;
+    }
     const int lds = ipx_dp_lds_bytes(8, 0, REV, maxcols, true, routing);
     const int pflag = pass | (ipx_dp_mc_in_lds(8, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
     uint8_t todo[IPX_MAX_EXACT + 1];
@@ -338,7 +364,7 @@ static inline uint32_t *ipx_plan_count_of(uint32_t *tables, int pass) { return t
 #define IPX_PLAN_TABLE_WORDS (IPX_NUM_PASSES * 2 * IPX_NUM_CLASSES)
 
 // tile size (alignments per wave) of the first 8-bit stage
-static inline int ipx_first_na(const IpxBatch &b, const IpxDims &d, int routing) { return (d.plain_first || ipx_low2_ok(b, d, routing)) ? 16 : 8; }
+static inline int ipx_first_na(const IpxBatch &b, const IpxDims &d, int routing) { return d.plain_first ? ipx_skew_na(d) : ipx_low2_ok(b, d, routing) ? 16 : 8; }
 
 // The job lists of the passes a job starts in (every record PENDING): they depend on the read lengths, the penalties
 // and the scoring parameters only, so they are built when a batch (or the parameters) changed, not in every run.
@@ -347,7 +373,7 @@ static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace
 {
     be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, 0), IPX_FIRST_DYNAMIC_PASS * 2 * IPX_NUM_CLASSES);
-    if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, 16, true);
+    if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, ipx_skew_na(d), true);
     if (b.score_size != 1) {
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_FIRST], IPX_PASS_BYTE_FIRST, ipx_first_na(b, d, routing), true);
         // jobs that start in the stepped pass: counted now, their count seeds that pass's (dynamic) row in every run
@@ -385,7 +411,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     const int prove_grid2 = prove_nchunk >= 512 ? (prove_grid1 + 1) / 2 : prove_grid1;
     if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
-        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing);
+        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, d.lat != 0);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], ws, d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, 3, word_from, 16);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
@@ -397,7 +423,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // lower-bound stage (compared with the plain outputs) and, failing that, the stepped pass.  (Jobs with gap_open <= gap_ext
             // start in the stepped pass: next_pass_key.)
             if (d.any_low) {
-                ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing);
+                ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing, d.lat != 0);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
                 if (!b.exact_direct) {
                     ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
@@ -431,8 +457,8 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         ipx_launch_dp<BE, 16, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_EXACT], ws, has8_all, maxcols, IPX_K_BYTE_EXACT, IPX_PASS_BYTE_EXACT, routing, 3, 0, 8);
     }
     if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
-        ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, 16, b.score_size == 1);
-        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing);
+        ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, ipx_skew_na(d), b.score_size == 1);
+        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, d.lat != 0);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], ws, b.score_size == 1 ? has16_all : d.has16_low, maxcols,
                                                      IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, 3, word_from, 16);
     }
@@ -440,22 +466,24 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         if (b.score_size != 1) {
             if (d.plain_first) {
                 // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
-                ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, 16);
-                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing);
+                ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, ipx_skew_na(d));
+                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing, d.lat != 0);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
             }
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
             ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], ws, has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing, 3, 0, 8);
         }
         if (b.score_size != 0) {
-            ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, 16);
-            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing);
+            ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, ipx_skew_na(d));
+            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, d.lat != 0);
             ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], ws, has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, 3, word_from, 16);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             // a SMALL batch has more SIMDs than jobs: one wave per job (k_tb_coop: a DP row spread over the lanes) then finishes a typical job in
             // a fifth of the time one lane needs for it (r03, 1000 jobs: 0.76 -> 0.42 ms of traceback), and the lane-per-job launch is skipped
-            const int tb_all_general = !(routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) && b.n_jobs <= (b.tb_diag ? IPX_TB_SMALL_DIAG : 2048);
+            // (with the anti-diagonal tiers: 1 = small batch, every job at 32 lanes at least; 2 = tiny batch, one job per wave)
+            const int tb_all_general = (routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) ? 0 : !b.tb_diag ? (b.n_jobs <= 2048 ? 1 : 0)
+                                       : b.n_jobs <= IPX_TB_TINY_DIAG ? 2 : b.n_jobs <= IPX_TB_SMALL_DIAG ? 1 : 0;
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 64, b, ws.tb_list, ws.tb_list_n, ws.tb_esc, tb_all_general,
                       ((routing & IPX_ROUTE_TB_NO_UNGAPPED) || tb_all_general) ? 0 : 1);   // (a small batch has a wave for every job: the check would only add its own latency)
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
@@ -622,7 +650,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
     for (int ps = 0; ps < IPX_NUM_PASSES; ++ps)
         for (int c = 0; c < IPX_NUM_CLASSES; ++c) d.cls_map[ps][c] = (uint8_t)c;
     memset(d.set, 0, sizeof d.set);
-    d.word_sets = d.plain_first = d.high_sets = 0;
+    d.word_sets = d.plain_first = d.high_sets = d.lat = 0;
     d.word_from = 0; d.plain_max_len = 0;
     const bool skew_ok = ipx_perm_profile_ok(b.mat, routing) && !(routing & (IPX_ROUTE_NO_F16 | IPX_ROUTE_NO_SKEW)) && b.f16_max_len > 0;
     if (!skew_ok) return;
@@ -644,7 +672,28 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
         if (!wfirst && c8 > all8) all8 = c8;
         if (!wfirst && c8 <= fmax8) { n8low[c8] += n; if (c8 > top8) top8 = c8; }
     }
-    if (merge && b.score_size != 0 && top16 >= 1) {
+    // latency tier (r04): a small batch, no job with gap_open <= gap_ext (those need the stepped kernels, whose tiles hold 8 or 16 reads:
+    // a pass has ONE tile size) and every 16-bit class within the wavefront kernels' reach.  Every class of a pass is then listed under the
+    // pass's longest one: ONE launch per pass -- on a chip with more SIMDs than the batch has tiles a launch lasts as long as its longest
+    // tile whatever its size, and two launches last twice that.
+    bool lat = merge && !(routing & IPX_ROUTE_NO_LAT) && (b.n_jobs <= IPX_LAT_MAX_JOBS || (routing & IPX_ROUTE_FORCE_LAT)) && all16 <= fmax16 && (all8 < 0 || 16 * all8 <= 8 * IPX_LAT_W);
+    for (int len = 0; lat && len <= IPX_MAX_READ_LEN; ++len) if (d.lenhist[1][len]) lat = false;
+    auto single_class = [](const uint32_t *n1, const uint32_t *n2, int top, uint8_t *map, uint8_t *set) {
+        int t = -1;
+        for (int c = top; c >= 0 && t < 0; --c) if (n1[c] || (n2 && n2[c])) t = c;
+        if (t < 0) return;
+        if (t < 1) t = 1;
+        set[t] = 1;
+        for (int c = 0; c <= t; ++c) map[c] = (uint8_t)t;
+    };
+    if (lat && b.score_size != 0 && top16 >= 1) {
+        d.lat = 1;
+        d.word_sets = 1;
+        d.word_from = fmax16 + 1;
+        single_class(n16wf, nullptr, top16, d.cls_map[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST]);
+        single_class(n16low, nullptr, top16, d.cls_map[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD]);
+        single_class(n16wf, n16low, top16, d.cls_map[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV]);      // (a prefix is never longer than its read)
+    } else if (merge && b.score_size != 0 && top16 >= 1) {
         d.word_sets = 1;
         d.word_from = fmax16 + 1;
         ipx_merge_classes(n16wf, top16, true, d.cls_map[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST]);
@@ -657,7 +706,12 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
     }
     // 8-bit passes as the plain recurrence
     const bool plain_ok = b.score_size != 1 && top8 >= 1;
-    if (plain_ok && b.use_bracket && !(routing & IPX_ROUTE_NO_PLAIN_FIRST)) {
+    if (d.lat && plain_ok && b.use_bracket && !(routing & IPX_ROUTE_NO_PLAIN_FIRST)) {
+        d.plain_first = 1;
+        d.plain_max_len = 16 * fmax8;
+        single_class(n8low, nullptr, top8, d.cls_map[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST]);
+        single_class(n8low, nullptr, top8, d.cls_map[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN]);
+    } else if (plain_ok && b.use_bracket && !(routing & IPX_ROUTE_NO_PLAIN_FIRST)) {
         d.plain_first = 1;
         d.plain_max_len = 16 * fmax8;
         ipx_merge_classes(n8low, top8, merge, d.cls_map[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST]);

@@ -507,7 +507,69 @@ def test_emu_anti_diagonal_traceback_tiers(emu, oracle_mod, port):
             assert res.as_dict(i) == exp[i], (routing, i, res.as_dict(i), exp[i])
         seen[routing] = a.tb_jobs
     coop, d16, d32, d64 = seen[0]
-    assert d16 >= 40 and d32 >= 8 and d64 >= 4 and 2 <= coop <= 12, seen      # small batch: every job starts in a tier; only bands past 63 reach k_tb_coop
-    assert d32 > sum(1 for f in first_bands if 16 <= f <= 31) or d64 > sum(1 for f in first_bands if 32 <= f <= 63), (seen, first_bands)   # some reach a tier by doubling out of the one below
-    assert seen[R.ROUTE_TB_NO_WAVE_PER_JOB][1] < d16                           # behind the lane-per-job kernels the first tier sees wide and doubled bands only
+    assert d16 == 0 and d32 >= 60 and d64 >= 4 and 2 <= coop <= 12, seen      # small batch: every job starts at 32 lanes at least; only bands past 63 reach k_tb_coop
+    big = seen[R.ROUTE_TB_NO_WAVE_PER_JOB]
+    assert big[2] > sum(1 for f in first_bands if 16 <= f <= 31) or big[3] > sum(1 for f in first_bands if 32 <= f <= 63), (seen, first_bands)   # some reach a tier by doubling out of the one below
+    assert 5 <= seen[R.ROUTE_TB_NO_WAVE_PER_JOB][1] < 40                       # behind the lane-per-job kernels the first tier sees wide and doubled bands only
     assert seen[R.ROUTE_TB_NO_DIAG][1:] == [0, 0, 0]
+    # a tiny batch: one job per wave
+    tiny = JobTable.from_sequences(reads[:56], refs, rid[:56], go[:56], ge[:56], encoded=True)
+    a = emu(0, 3, 2)
+    res = a.align(tiny)
+    assert a.status == 0 and all(res.as_dict(i) == exp[i] for i in range(56))
+    assert a.tb_jobs[1] == 0 and a.tb_jobs[2] == 0 and a.tb_jobs[3] >= 40, a.tb_jobs
+
+def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
+    """r04, k_dp_skew<S, REV, BH, 32>: the wavefront passes of a small batch at 32 lanes per read (four reads per wave, every class of a pass
+    in one launch, a whole-wavefront lane shift).  Reads of 1..256 bp against windows shorter and longer than the reads, with N, with
+    indels, empty reads; gap penalties with gap_open > gap_ext only (anything else keeps the batch off the tier); scorings that put reads
+    in the 16-bit passes (3,2), in the plain 8-bit flow (1,1) and in both (2,2); every field and CIGAR against the oracle, and the same
+    batch with the tier forced off.  (ROUTE_FORCE_LAT: the emulator build never takes the tier by itself.)"""
+    rng = np.random.default_rng(3232)
+    refs = [rng.integers(0, 4, int(n)).astype(np.int8) for n in (40, 160, 300, 333, 610)]
+    refs[3][rng.integers(0, 333, 20)] = 4
+    reads, rid, go, ge = [], [], [], []
+    gaps = [(3, 1), (3, 0), (5, 1), (4, 0), (2, 1), (10, 1), (255, 1)]
+    for i in range(90):
+        k = int(rng.integers(0, len(refs)))
+        w = refs[k]
+        L = int(rng.integers(1, 257)) if i % 7 else (1, 7, 8, 9, 31, 32, 33, 64, 65, 128, 255, 256, 0)[(i // 7) % 13]
+        st = int(rng.integers(0, max(1, len(w) - 10)))
+        r = np.resize(w[st:], L).copy() if L else np.zeros(0, np.int8)
+        if L > 20 and i % 3 == 0:
+            cut = int(rng.integers(5, L - 5))
+            r = np.concatenate([r[:cut], r[cut + 1 + i % 4:]])
+        if L > 20 and i % 3 == 1:
+            cut = int(rng.integers(5, L - 5))
+            r = np.concatenate([r[:cut], rng.integers(0, 4, 1 + i % 3).astype(np.int8), r[cut:]])[:256]
+        m = rng.random(len(r)) < (0.0, 0.03, 0.12)[i % 3]
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        if i % 11 == 0 and len(r):
+            r[rng.integers(0, len(r), max(1, len(r) // 9))] = 4
+        if i % 13 == 5:
+            r = rng.integers(0, 4, len(r)).astype(np.int8)
+        g = gaps[i % len(gaps)]
+        reads.append(r); rid.append(k); go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+    K_WORD_FIRST, K_WORD_REV, K_BYTE_PLAIN = 6, 9, 14          # IPX_K_* of csrc/ipx_pipeline.h
+    for scoring in ((3, 2), (1, 1), (2, 2)):
+        mat = oracle_mod.dna_matrix(*scoring)
+        exp = [port.align(r, refs[rid[i]], mat, go[i], ge[i]) for i, r in enumerate(reads)]
+        got = {}
+        for routing in (R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST):
+            a = emu(0, *scoring)
+            a.set_routing(routing)
+            res = a.align(jobs)
+            assert a.status == 0
+            for i in range(len(reads)):
+                assert res.as_dict(i) == exp[i], (scoring, routing, i, len(reads[i]), res.as_dict(i), exp[i])
+            got[routing] = {kc: sorted(c for c in range(140) if a.launches.get(a.key(kc, c))) for kc in (K_WORD_FIRST, K_WORD_REV, K_BYTE_PLAIN)}
+        lat = got[R.ROUTE_FORCE_LAT]
+        assert all(len(v) <= 1 for v in lat.values()), lat                       # one launch per pass on the tier ...
+    # a job with gap_open <= gap_ext keeps the whole batch off the tier (its stepped kernels have tiles of their own size)
+    jobs2 = JobTable.from_sequences(reads[:20], refs, rid[:20], [3] * 19 + [1], [1] * 19 + [1], encoded=True)
+    a = emu(0, 3, 2)
+    a.set_routing(R.ROUTE_FORCE_LAT)
+    res = a.align(jobs2)
+    mat = oracle_mod.dna_matrix(3, 2)
+    assert a.status == 0 and all(res.as_dict(i) == port.align(reads[i], refs[rid[i]], mat, 3 if i < 19 else 1, 1) for i in range(20))

@@ -73,14 +73,18 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True, fast_gaps_only=False):
                                            ((3, 2), (R.ROUTE_TB_NO_UNGAPPED,)), ((1, 3), (R.ROUTE_TB_NO_UNGAPPED, "fast_gaps")),
                                            # r04: the anti-diagonal traceback tiers off; small batches (every traceback in a tier: "small" = 6 000 jobs)
                                            ((3, 2), (R.ROUTE_TB_NO_DIAG,)), ((2, 2), (R.ROUTE_TB_NO_DIAG, "fast_gaps")),
-                                           ((3, 2), ("small",)), ((1, 1), ("small",)), ((2, 4), ("small", "fast_gaps")), ((3, 2), ("small", R.ROUTE_TB_NO_DIAG))])
+                                           ((3, 2), ("small",)), ((1, 1), ("small",)), ((2, 4), ("small", "fast_gaps")), ((3, 2), ("small", R.ROUTE_TB_NO_DIAG)),
+                                           # r04: the latency tier of the wavefront passes (32 lanes per read) forced on a whole batch / off for a small one; tiny batches
+                                           ((3, 2), (R.ROUTE_FORCE_LAT, "fast_gaps")), ((1, 1), (R.ROUTE_FORCE_LAT, "fast_gaps")), ((2, 2), (R.ROUTE_FORCE_LAT, "fast_gaps")),
+                                           ((5, 4), (R.ROUTE_FORCE_LAT, "fast_gaps")), ((3, 2), ("small", "fast_gaps")), ((3, 2), ("small", "fast_gaps", R.ROUTE_NO_LAT)),
+                                           ((3, 2), ("tiny", "fast_gaps")), ((1, 1), ("tiny",))])
 def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd):
     from oracle.oracle import cpu_batch_results, fnv1a_ops
     fast = "fast_gaps" in knobs
     routing = sum(k for k in knobs if isinstance(k, int))
-    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs) + (5000 if fast else 0) + (77 if "small" in knobs else 0)
+    rng = np.random.default_rng(1000 + 7 * scoring[0] + scoring[1] + 100 * len(knobs) + (5000 if fast else 0) + (77 if "small" in knobs else 0) + (99 if "tiny" in knobs else 0)
                                 + 100000 * int(os.environ.get("IPX_STRESS_SEED", "0")))
-    n = 6000 if "small" in knobs else int(os.environ.get("IPX_STRESS_JOBS", "30000"))
+    n = 6000 if "small" in knobs else 900 if "tiny" in knobs else int(os.environ.get("IPX_STRESS_JOBS", "30000"))
     jobs = _make_jobs(rng, n, 97, fast_gaps_only=fast)
     be = oracle_mod.Backend("reference" if oracle_mod.have_reference() else "port")
     mat = oracle_mod.dna_matrix(*scoring)
@@ -125,7 +129,7 @@ def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "stress_undefined_traceback.jsonl"), "a") as f:
             f.write(json.dumps(counts) + "\n")
-    assert int(undefined.sum()) <= n // 200, "implausibly many undefined tracebacks: %d" % int(undefined.sum())
+    assert int(undefined.sum()) <= max(8, n // 200), "implausibly many undefined tracebacks: %d" % int(undefined.sum())
     first = np.flatnonzero(bad)
     assert len(first) == 0, "scoring %s: %d jobs differ, first %d: gpu %s cpu %s" % (
         scoring, len(first), first[0], rec[first[0]], exp[first[0]])
