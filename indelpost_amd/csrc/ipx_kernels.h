@@ -137,13 +137,32 @@ IPX_KERNEL void k_pack_refs(const int8_t *IPX_RESTRICT refs, const int64_t *IPX_
 // ------------------------------------------------------------------------------------------------
 // k_init: result records start as "nothing aligned yet" (ssw.c:831-836)
 // ------------------------------------------------------------------------------------------------
-IPX_KERNEL void k_init(IpxBatch b)
+// r04: block 0 also resets the small per-run tables -- CIGAR cursor, status word, traceback list counters, the dynamic passes' count and
+// cursor rows (seeded with the jobs that START in the stepped pass) -- which were four fill / copy commands of their own on the stream,
+// ~6 us each with nothing to overlap in a small call.
+struct IpxRunReset {
+    uint32_t *cursor;            // 1 word (null: nothing to reset, e.g. the launch that only prepares the static plans)
+    uint32_t *status;            // 1 word, or null (the caller has cleared it)
+    uint32_t *tb_n;              // IPX_TB_NCOUNTERS words
+    uint32_t *dyn;               // dyn_words words: count + cursor rows of the dynamic passes
+    int32_t dyn_words;
+    uint32_t *exact_dst;         // IPX_NUM_CLASSES words <- exact_src (after dyn is zeroed: the row lies inside it), or null
+    const uint32_t *exact_src;
+};
+IPX_KERNEL void k_init(IpxBatch b, IpxRunReset z)
 {
     for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
         IpxResult r;
         r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
         r.ref_end2 = 0; r.cigar_off = 0; r.cigar_len = 0; r.flag = 0; r.mode = IPX_MODE_PENDING;
         b.res[i] = r;
+    }
+    if (IPX_BID == 0 && z.cursor) {
+        if (IPX_TID == 0) { z.cursor[0] = 0; if (z.status) z.status[0] = 0; }
+        for (int q = IPX_TID; q < 12; q += IPX_BDIM) z.tb_n[q] = 0;                 // (IPX_TB_NCOUNTERS)
+        for (int q = IPX_TID; q < z.dyn_words; q += IPX_BDIM) z.dyn[q] = 0;
+        IPX_SYNC();
+        if (z.exact_dst) for (int q = IPX_TID; q < IPX_NUM_CLASSES; q += IPX_BDIM) z.exact_dst[q] = z.exact_src[q];
     }
 }
 
@@ -1283,8 +1302,24 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
 // reference, i.e. through private memory)
 #if defined(IPX_CPU_EMU)
 #define IPX_NOINLINE_DEV static
+// (emulator: plain references)
+#define IPX_CALLEE_DESC_PARAMS const IpxBatch &b, const IpxPlan &p,
+#define IPX_CALLEE_DESC_ARGS b, p,
+#define IPX_CALLEE_DESC_LOCALS
 #else
 #define IPX_NOINLINE_DEV __device__ __attribute__((noinline))
+// r04: the called bodies do NOT receive the batch and plan descriptors.  Passed by reference, the caller had to materialise both structs
+// in private memory -- 288-368 bytes per LANE, written by every wave of every tier launch before its first tile (a launch that found
+// nothing still wrote a quarter of a gigabyte) and read back by the callee.  Every kernel that calls these bodies takes (IpxBatch b,
+// IpxPlan p, ...) as its first two arguments, so the callee reads them where they already are: the kernel-argument segment, through a
+// wave-uniform pointer (scalar loads, no private memory).
+#define IPX_KERNARG_AS __attribute__((address_space(4)))
+#define IPX_CALLEE_DESC_PARAMS
+#define IPX_CALLEE_DESC_ARGS
+#define IPX_CALLEE_DESC_LOCALS                                                                                                      \
+    const IPX_KERNARG_AS char *ka_ = (const IPX_KERNARG_AS char *)__builtin_amdgcn_kernarg_segment_ptr();                              \
+    const IpxBatch b = *(const IPX_KERNARG_AS IpxBatch *)ka_;                                                                        \
+    const IpxPlan p = *(const IPX_KERNARG_AS IpxPlan *)(ka_ + ((sizeof(IpxBatch) + alignof(IpxPlan) - 1) & ~(alignof(IpxPlan) - 1)));
 #endif
 
 // k_dp_pass_tier (r03): the STEPPED 8-bit passes (exact stage, forward and reverse; selector profile, fast gaps) of the classes
@@ -1296,8 +1331,9 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
 #define IPX_PASS_TIER_LO 0                      // classes the launch covers (8-bit segLen: reads of up to 256 bp; 0 = empty reads)
 #define IPX_PASS_TIER_HI 16
 template <int W, int S, bool REV, int STAGE>
-IPX_NOINLINE_DEV void dp_pass_body_call(const IpxBatch &b, const IpxPlan &p, int maxcols, int pass, uint32_t rank, uint32_t nrank)
+IPX_NOINLINE_DEV void dp_pass_body_call(IPX_CALLEE_DESC_PARAMS int maxcols, int pass, uint32_t rank, uint32_t nrank)
 {
+    IPX_CALLEE_DESC_LOCALS
     dp_pass_body<W, S, REV, true, STAGE, true, false, false>(b, p, S, S, maxcols, pass, (uint64_t)0, (uint64_t)0, rank, nrank);
 }
 template <int W, int SLO, int SHI, bool REV, int STAGE>
@@ -1307,7 +1343,7 @@ IPX_DEV void dp_pass_tier_walk(uint32_t set_mask, const IpxBatch &b, const IpxPl
         if ((set_mask >> SLO) & 1u) {
             const uint32_t n = p.tile_off[SLO + 1] - p.tile_off[SLO], nb = (uint32_t)IPX_GDIM;
             const uint32_t rank = ((uint32_t)IPX_BID + nb - base % nb) % nb;      // this block's rank for the class: its tiles follow the classes before it
-            if (rank < n) dp_pass_body_call<W, SLO, REV, STAGE>(b, p, maxcols, pass, rank, nb);
+            if (rank < n) dp_pass_body_call<W, SLO, REV, STAGE>(IPX_CALLEE_DESC_ARGS maxcols, pass, rank, nb);
             base += n;
         }
         dp_pass_tier_walk<W, SLO + 1, SHI, REV, STAGE>(set_mask, b, p, maxcols, pass, base);
@@ -1715,9 +1751,10 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
 // land in all of them; called, each keeps the allocation of its stand-alone kernel (the batch and plan descriptors travel by
 // reference, i.e. through private memory -- they are read in the tile's set-up and finalisation only, never in the column loop)
 template <int SMAX, bool REV, int BH>
-IPX_NOINLINE_DEV void dp_skew_tile_call(const IpxBatch &b, const IpxPlan &p, const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
+IPX_NOINLINE_DEV void dp_skew_tile_call(IPX_CALLEE_DESC_PARAMS const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
                                         unsigned char *lds, const uint32_t nz)
 {
+    IPX_CALLEE_DESC_LOCALS
     dp_skew_tile<SMAX, REV, BH>(b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
 }
 // (tier kernels) the tile body of class c, c a compile-time-unrollable value in [SLO / STEP, SHI / STEP]
@@ -1726,7 +1763,7 @@ IPX_DEV void dp_skew_tile_at(int c, const IpxBatch &b, const IpxPlan &p, uint32_
 {
     constexpr int STEP = BH ? 2 : 1;
     if constexpr (SLO <= SHI) {
-        if (c == SLO / STEP) dp_skew_tile_call<SLO, REV, BH>(b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
+        if (c == SLO / STEP) dp_skew_tile_call<SLO, REV, BH>(IPX_CALLEE_DESC_ARGS first, cnt, pass, maxcol, mc_lds, lds, nz);
         else dp_skew_tile_at<SLO + STEP, SHI, REV, BH>(c, b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
     }
 }
@@ -2236,6 +2273,124 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
     drain(true);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_prove_overflow_diag (r04, latency tier): the same proof for a SMALL batch, EIGHT LANES PER READ.  k_prove_overflow gives a read one
+// lane, which walks up to 150 band rows of 15 cells one after the other (and the ungapped diagonal before that): 0.13 ms however few
+// reads there are -- a quarter of a 1 000-job call.  Here the band of IPX_PROVE_BAND = 15 diagonals is an anti-diagonal wavefront (as in
+// k_tb_diag: lane kl owns band diagonals 2 kl and 2 kl + 1, a cell's left and upper neighbours are one step old, the diagonal one two):
+// 2 x rows steps of a few dozen instructions.  The cells are prove_band<15>'s, move for move (the ungapped test is the band's middle
+// diagonal alone and needs no pass of its own); any sound proof gives the same results, it only decides which reads skip the 8-bit pass.
+// Dynamic LDS: 64 B score table | per group of 8 lanes: row score words 8 x 256 | band window letters 272
+// ------------------------------------------------------------------------------------------------
+#define IPX_PROVED_ROWS 256
+static inline int ipx_proved_lds_bytes() { return 64 + 8 * (8 * IPX_PROVED_ROWS + IPX_PROVED_ROWS + 16); }
+IPX_KERNEL_WAVE void k_prove_overflow_diag(IpxBatch b)
+{
+    constexpr int BW = IPX_PROVE_BAND, HB = BW / 2, ROWS = IPX_PROVED_ROWS, GB = 8 * ROWS + ROWS + 16;
+    static_assert(BW == 15, "eight lanes hold fifteen diagonals");
+    const int lane = lane_id(), kl = lane & 7, g = lane >> 3;
+    unsigned char *lds = IPX_LDS_BASE;
+    uint64_t *coltab = (uint64_t *)lds;                             // [read letter a] -> bytes mat[c][a], c = 0..4 (bytes 5..7 = 0: a column outside the window scores 0)
+    uint64_t *srow = (uint64_t *)(lds + 64 + g * GB);               // [row] -> coltab[read letter]
+    int8_t *sref = (int8_t *)(srow + ROWS);                         // [band column t = column - (d0 - HB)] -> window letter x 8; 56 = outside the window
+    if (lane < 5) {
+        uint64_t t = 0;
+        for (int c = 0; c < 5; ++c) t |= (uint64_t)(uint8_t)b.mat[c * 5 + lane] << (8 * c);
+        coltab[lane] = t;
+    }
+    IPX_SYNC();
+    const int cap = 255 - b.bias;
+    const uint32_t lowmask = kl == 0 ? 0u : 0xFFFFFFFFu;
+    for (int64_t base = (int64_t)IPX_BID * 8; base < b.n_jobs; base += (int64_t)IPX_GDIM * 8) {      // (uniform)
+        const int64_t i = base + g;
+        IpxResult r;
+        bool mine = false;
+        int Lr = 0, go = 1, ge = 0, rows = 0, S8 = 1;
+        if (i < b.n_jobs) {
+            r = b.res[i];
+            Lr = (int)(b.read_off[i + 1] - b.read_off[i]);
+            mine = r.mode == IPX_MODE_WORD_UNPROVEN;
+            if (mine) {
+                go = b.gap_open[i]; ge = b.gap_ext[i];
+                rows = r.read_end1 + 1;
+                S8 = (Lr + 15) >> 4;                                  // segLen of the 8-bit pass (ssw.c:166)
+                if (S8 < 1) S8 = 1;
+            }
+        }
+        const bool fits = rows >= 1 && rows <= ROWS;                  // (longer: left to the 8-bit pass; the tier takes reads of up to 256 bp)
+        IPX_SYNC();                                                   // the previous job's letters are no longer read
+        if (mine && fits) {
+            const int rid = b.ref_id[i];
+            const int8_t *rd = b.reads + b.read_off[i];
+            const int8_t *rf = b.refs_packed + b.refp_off[rid];
+            const int refLen = b.ref_len[rid];
+            const int cb = r.ref_end1 - r.read_end1 - HB;             // window column of band column 0
+            for (int q = kl; q < rows; q += 8) { const int a = rd[q]; srow[q] = coltab[(unsigned)a > 4u ? 4 : a]; }
+            for (int q = kl; q < rows + 16; q += 8) { const int c = cb + q; sref[q] = (int8_t)((c >= 0 && c < refLen) ? rf[c] * 8 : 56); }
+        }
+        IPX_SYNC();
+        const bool run = mine && fits;
+        const int TH = (int)xl_first(wave_umax(run ? (uint32_t)(rows + 7) : 0u));       // hi = row + kl
+        int Hme = 0, Hfe = 0, Fe = 0, Ee = 0, Hmo = 0, Hfo = 0, Fo = 0, Eo = 0;
+        bool proven = false;
+        int seg = (S8 - kl % S8) % S8;                                // row % segLen of this lane's row, hi = 0: row = -kl
+        auto row8 = [&](int rr) -> uint64_t { return srow[rr < 0 ? 0 : rr > ROWS - 1 ? ROWS - 1 : rr]; };
+        auto ref8 = [&](int t) -> int { return (int)sref[t < 0 ? 0 : t > ROWS + 15 ? ROWS + 15 : t] & 56; };
+        uint64_t mrow_n = row8(-kl);
+        int rc0 = ref8(-kl + 2 * kl), rc1 = ref8(-kl + 2 * kl + 1);    // band column of (row, diagonal q) = row + q
+        for (int hi = 0; hi < TH; ++hi) {
+            if ((hi & 15) == 15) {                                    // every read of the wave proven (or done): nothing left to find
+                const uint32_t pg = group_or<8>(proven ? 1u : 0u);
+                if (!xl_any(run && pg == 0u && hi < rows + 7)) break;
+            }
+            const int rr = hi - kl;
+            const uint64_t mrow = mrow_n;
+            mrow_n = row8(rr + 1);
+            const int rcn = ref8(rr + 2 * kl + 2);                    // the odd cell's band column in the next step
+            const bool rowok = run && rr >= 0 && rr < rows;
+            const bool cross = seg == 0;                              // first row of a segment: a vertical gap enters through lazy-F's first step only
+            // ---- even step: diagonal 2 kl ----
+            {
+                const int Hl = (int)(xl_row_shr1((uint32_t)Hmo) & lowmask), El = (int)(xl_row_shr1((uint32_t)Eo) & lowmask);
+                int f = Fo - ge; { const int f2 = Hmo - go; f = f > f2 ? f : f2; f = f > 0 ? f : 0; }
+                int e = El - ge; { const int e2 = Hl - go; e = e > e2 ? e : e2; e = e > 0 ? e : 0; }
+                int hm = Hfe + (int)(int8_t)(mrow >> rc0);
+                hm = hm > e ? hm : e; hm = hm > 0 ? hm : 0;
+                int hf, fk;
+                if (!cross) { hm = hm > f ? hm : f; hf = hm; fk = f; }
+                else { hf = hm > f ? hm : f; fk = 0; }
+                if (rowok && hf >= cap && rc0 != 56) proven = true;
+                Hme = rowok ? hm : 0; Hfe = rowok ? hf : 0; Fe = rowok ? fk : 0; Ee = rowok ? e : 0;
+            }
+            // ---- odd step: diagonal 2 kl + 1 (the eighth lane has none) ----
+            {
+                const int Fu = (int)xl_row_shl1((uint32_t)Fe), Hu = (int)xl_row_shl1((uint32_t)Hme);
+                const bool ok = rowok && kl < 7;
+                int f = Fu - ge; { const int f2 = Hu - go; f = f > f2 ? f : f2; f = f > 0 ? f : 0; }
+                int e = Ee - ge; { const int e2 = Hme - go; e = e > e2 ? e : e2; e = e > 0 ? e : 0; }
+                int hm = Hfo + (int)(int8_t)(mrow >> rc1);
+                hm = hm > e ? hm : e; hm = hm > 0 ? hm : 0;
+                int hf, fk;
+                if (!cross) { hm = hm > f ? hm : f; hf = hm; fk = f; }
+                else { hf = hm > f ? hm : f; fk = 0; }
+                if (ok && hf >= cap && rc1 != 56) proven = true;
+                Hmo = ok ? hm : 0; Hfo = ok ? hf : 0; Fo = ok ? fk : 0; Eo = ok ? e : 0;
+            }
+            rc0 = rc1; rc1 = rcn;
+            if (++seg == S8) seg = 0;
+        }
+        const bool pj = group_or<8>(proven ? 1u : 0u) != 0u;
+        int key = -1;
+        if (mine && kl == 0) {
+            // not proven: the 8-bit pass decides (k_prove_overflow's rule for which of its stages comes first)
+            const bool likely = 2 * Lr * b.max_match >= 3 * (255 - b.bias);
+            r.mode = pj ? IPX_MODE_WORD : ((b.exact_direct && !likely) ? IPX_MODE_NEED_BYTE_EXACT_W : IPX_MODE_NEED_BYTE_CHECK);
+            b.res[i] = r;
+            key = next_pass_key(b, r, Lr, b.gap_open[i] <= b.gap_ext[i]);
+        }
+        plan_note(b, key);
+    }
+}
 // ------------------------------------------------------------------------------------------------
 // k_prove_plain<REV>: certify, from BELOW, an output of the plain recurrence that k_dp_skew (BH = 2) has put into the record.
 //
@@ -3243,16 +3398,15 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
             uint32_t word = 0;
             // letters one step ahead: the row's score word and the window letter of the odd cell (= the even cell's of the next row)
             const int jbase = 2 * kl - sbw - kl;                      // j0 = hi + jbase
-            auto ref8 = [&](int j) -> int { return (j >= 0 && j < refLen) ? (int)sref[j] : 0; };
-            uint64_t mrow_n = (mine && -kl >= 0 && -kl < readLen) ? srow[-kl] : 0ull;
-            int rc0 = mine ? ref8(jbase) : 0, rc1 = mine ? ref8(jbase + 1) : 0;
+            // (loaded whether the cell exists or not, from a clamped index: the score of a cell that does not exist is never used)
+            auto ref8 = [&](int j) -> int { return (int)sref[j < 0 ? 0 : j > REFCAP - 1 ? REFCAP - 1 : j] & 56; };
+            auto row8 = [&](int i2) -> uint64_t { return srow[i2 < 0 ? 0 : i2 > ROWS - 1 ? ROWS - 1 : i2]; };
+            uint64_t mrow_n = row8(-kl);
+            int rc0 = ref8(jbase), rc1 = ref8(jbase + 1);
             for (int hi = 0; hi < TH; ++hi) {
                 const uint64_t mrow = mrow_n;
-                {   // next step's letters (independent of the recurrence: the loads overlap it)
-                    const int in = hi + 1 - kl;
-                    mrow_n = (mine && in >= 0 && in < readLen) ? srow[in] : 0ull;
-                }
-                const int rcn = mine ? ref8(hi + jbase + 2) : 0;
+                mrow_n = row8(hi + 1 - kl);                            // next step's letters (independent of the recurrence: the loads overlap it)
+                const int rcn = ref8(hi + jbase + 2);
                 // ---- even step: diagonal 2 kl ----
                 {
                     const int Hl = (int)(tbd_from_lower<LG>((uint32_t)Ho) & lowmask), Fl = (int)(tbd_from_lower<LG>((uint32_t)Fo) & lowmask);
@@ -3334,6 +3488,30 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
                     if (q <= 2 * fbw && (hh >> 2) < nwords) {
                         const int widx = (hh >> 2) * LG + lk;
                         if (widx != cidx) { cw = dw[widx]; cidx = widx; }
+                        // A RUN OF MATCHES in one go: the word holds the lane's cells of rows hh&~3 .. hh (same diagonal: a diagonal move keeps
+                        // q), codes 1..4 = "H came from the diagonal".  While the walk is in the H plane and stays inside the rectangle
+                        // (ssw.c:679: i >= 0 && j > 0 before every step) those steps are all case 1 (ssw.c:681-687).
+                        if (plane == 2 && row == i) {
+                            const int avail = (hh & 3) + 1;
+                            const uint32_t t = (cw >> (4 * (q & 1))) & 0x0F0F0F0Fu;
+                            uint32_t bad = (((t + 0x03030303u) & 0x0C0C0C0Cu) ^ 0x04040404u) << (8 * (4 - avail));   // byte != 0: not a diagonal code; this row's byte on top
+                            int rn = bad ? (int)(__builtin_clz(bad) >> 3) : avail;
+                            if (rn > avail) rn = avail;
+                            if (rn > i + 1) rn = i + 1;
+                            if (rn > j) rn = j;
+                            if (rn > 1) {
+                                i -= rn; j -= rn; op = 0;
+                                if (prev == 0) e += rn;
+                                else {
+                                    ++lcnt;
+                                    if (lcnt + 2 > IPX_TBD_CIG) { full = true; break; }
+                                    cig[lcnt - 1] = ((uint32_t)e << 4) | (uint32_t)prev;
+                                    prev = 0;
+                                    e = rn;
+                                }
+                                continue;
+                            }
+                        }
                         const int v = (int)((cw >> (8 * (hh & 3) + 4 * (q & 1))) & 15u);
                         if (v) {
                             const int de = 2 + ((v - 1) & 1), df = 4 + (((v - 1) >> 1) & 1), dh = (v - 1) >> 2;

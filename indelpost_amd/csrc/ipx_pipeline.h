@@ -371,7 +371,9 @@ static inline int ipx_first_na(const IpxBatch &b, const IpxDims &d, int routing)
 template <class BE>
 static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing)
 {
-    be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
+    IpxRunReset nothing;
+    memset(&nothing, 0, sizeof nothing);
+    be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b, nothing);
     be.zero_u32(ipx_plan_count_of(ws.plan_tables, 0), IPX_FIRST_DYNAMIC_PASS * 2 * IPX_NUM_CLASSES);
     if (b.score_size == 2) ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FIRST], IPX_PASS_WORD_FIRST, ipx_skew_na(d), true);
     if (b.score_size != 1) {
@@ -384,16 +386,23 @@ static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace
 }
 
 template <class BE>
-static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing)
+static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing, bool reset_status = false)
 {
+    static_assert(IPX_TB_NCOUNTERS == 12, "k_init resets twelve traceback counters");
     const int maxcols = d.max_ref_len + 4;
     uint8_t has8_all[IPX_NUM_CLASSES], has16_all[IPX_NUM_CLASSES];
     for (int c = 0; c < IPX_NUM_CLASSES; ++c) { has8_all[c] = d.has8_low[c] | d.has8_wf[c]; has16_all[c] = d.has16_low[c] | d.has16_wf[c]; }
-    be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b);
-    be.zero_u32(b.cigar_cursor, 1);
-    be.zero_u32(ws.tb_list_n, IPX_TB_NCOUNTERS);
-    be.zero_u32(ipx_plan_count_of(ws.plan_tables, IPX_FIRST_DYNAMIC_PASS), (IPX_NUM_PASSES - IPX_FIRST_DYNAMIC_PASS) * 2 * IPX_NUM_CLASSES);
-    if (b.score_size != 1) be.copy_u32(ws.plan[IPX_PASS_BYTE_EXACT].count, ws.exact_starters, IPX_NUM_CLASSES);
+    {   // records back to "nothing aligned yet", and (block 0) the small per-run tables: one launch where there were five commands
+        IpxRunReset z;
+        memset(&z, 0, sizeof z);
+        z.cursor = b.cigar_cursor;
+        z.status = reset_status ? b.status : nullptr;
+        z.tb_n = ws.tb_list_n;
+        z.dyn = ipx_plan_count_of(ws.plan_tables, IPX_FIRST_DYNAMIC_PASS);
+        z.dyn_words = (IPX_NUM_PASSES - IPX_FIRST_DYNAMIC_PASS) * 2 * IPX_NUM_CLASSES;
+        if (b.score_size != 1) { z.exact_dst = ws.plan[IPX_PASS_BYTE_EXACT].count; z.exact_src = ws.exact_starters; }
+        be.launch(IPX_KEY(IPX_K_INIT, 0), k_init, be.flat_grid(b.n_jobs), 256, 0, b, z);
+    }
 
     const bool low2 = ipx_low2_ok(b, d, routing);                 // 8-bit lower-bound launches: 16 reads per wave (k_dp_pass VL2)
     if (low2) routing |= IPX_ROUTE_INTERNAL_VL2;
@@ -415,6 +424,10 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], ws, d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, 3, word_from, 16);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
+        if (d.lat && !(routing & IPX_ROUTE_NO_LAT_PROOF)) {       // latency tier: eight lanes per read (every read of the batch is within its reach: <= 256 bp)
+            const int64_t pg = (b.n_jobs + 7) / 8;
+            be.launch(IPX_KEY(IPX_K_PROVE, 1), k_prove_overflow_diag, (int)(pg < prove_cap ? pg : prove_cap), 64, ipx_proved_lds_bytes(), b);
+        } else
         be.launch(IPX_KEY(IPX_K_PROVE, 0), k_prove_overflow, prove_grid1, 64, ipx_prove_lds_bytes(cap), b, cap, prove_chunk);
     }
     if (b.score_size != 1) {                                     // 8-bit forward pass (ssw.c:842-843)

@@ -474,7 +474,8 @@ int ipx_run(ipx_ctx *c)
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;
     HipBackend be{c};
-    be.zero_u32(b.status, 1);
+    const bool first_run = !c->static_valid && c->n_jobs > 0;
+    if (first_run || c->n_jobs == 0) be.zero_u32(b.status, 1);   // (later runs: k_init clears it with the other per-run tables)
     if (!c->static_valid && c->n_jobs > 0) {
         // first run of this batch under these parameters: the job lists of the passes every job starts in
         ipx_plan_classes(c->dims, b, c->routing);
@@ -491,7 +492,7 @@ int ipx_run(ipx_ctx *c)
         c->static_valid = true;
     }
     HIPCHK(hipEventRecord(c->run_start, c->stream));
-    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims, c->routing);
+    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims, c->routing, !first_run);
     ++c->runs_since_sync;
     HIPCHK(hipEventRecord(c->run_stop, c->stream));
     if (be.err != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }

@@ -556,7 +556,7 @@ def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
         mat = oracle_mod.dna_matrix(*scoring)
         exp = [port.align(r, refs[rid[i]], mat, go[i], ge[i]) for i, r in enumerate(reads)]
         got = {}
-        for routing in (R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST):
+        for routing in (R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT_PROOF):
             a = emu(0, *scoring)
             a.set_routing(routing)
             res = a.align(jobs)
