@@ -1307,7 +1307,7 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
 #define IPX_CALLEE_DESC_ARGS b, p,
 #define IPX_CALLEE_DESC_LOCALS
 #else
-#define IPX_NOINLINE_DEV __device__ __attribute__((noinline))
+#define IPX_NOINLINE_DEV static __device__ __attribute__((noinline))
 // r04: the called bodies do NOT receive the batch and plan descriptors.  Passed by reference, the caller had to materialise both structs
 // in private memory -- 288-368 bytes per LANE, written by every wave of every tier launch before its first tile (a launch that found
 // nothing still wrote a quarter of a gigabyte) and read back by the callee.  Every kernel that calls these bodies takes (IpxBatch b,
@@ -1318,8 +1318,8 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
 #define IPX_CALLEE_DESC_ARGS
 #define IPX_CALLEE_DESC_LOCALS                                                                                                      \
     const IPX_KERNARG_AS char *ka_ = (const IPX_KERNARG_AS char *)__builtin_amdgcn_kernarg_segment_ptr();                              \
-    const IpxBatch b = *(const IPX_KERNARG_AS IpxBatch *)ka_;                                                                        \
-    const IpxPlan p = *(const IPX_KERNARG_AS IpxPlan *)(ka_ + ((sizeof(IpxBatch) + alignof(IpxPlan) - 1) & ~(alignof(IpxPlan) - 1)));
+    const IpxBatch &b = *(const IpxBatch *)ka_;                        /* (the compiler infers the constant address space back) */    \
+    const IpxPlan &p = *(const IpxPlan *)(ka_ + ((sizeof(IpxBatch) + alignof(IpxPlan) - 1) & ~(alignof(IpxPlan) - 1)));
 #endif
 
 // k_dp_pass_tier (r03): the STEPPED 8-bit passes (exact stage, forward and reverse; selector profile, fast gaps) of the classes
