@@ -62,7 +62,7 @@ def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
             t0 = time.perf_counter()
             table = JobTable.concat(loci)
             t1 = time.perf_counter()
-            parts = g.align(table).split([t.n_jobs for t in loci])
+            parts = g.align(table).split(table.table_jobs)
             t2 = time.perf_counter()
             t_cat += t1 - t0
             t_all += t2 - t0
@@ -72,7 +72,8 @@ def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
                 "n_loci": n_loci, "jobs_per_locus": per, "n_jobs": jobs.n_jobs, "concat_ms_per_step": round(t_cat / steps * 1e3, 3),
                 "digest": whole.digest(), "sum_score1": int(whole.records["score1"].astype(np.int64).sum()),
                 "note": "host memory to host memory through align_loci (concat + H2D + pipeline + D2H + split); compare with configs.5, "
-                        "the same jobs resident in HBM"}
+                        "the same jobs resident in HBM.  The per-locus tables are the caller's (made outside the timed region, their ten-integer "
+                        "descriptors cached by the warm-up calls: a table handed over for the first time costs ~8 us more)"}
     finally:
         g.close()
 

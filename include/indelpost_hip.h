@@ -182,6 +182,15 @@ int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out12);  /* traceback routing of t
  * (no terminators); off[i]..off[i+1] delimits job i (empty for a job without CIGAR), off has n+1 entries.
  * Returns the total length, or -(needed length) when `cap` is too small (nothing is written then). */
 int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, char *out, int64_t cap, int64_t *off);
+/* host-side helper, many loci as ONE batch: concatenate n_tables per-locus job tables (the arrays ipx_upload takes, one set per locus).
+ * desc: n_tables x 10 int64 = addresses of reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len (0: none), then n_jobs, n_refs.
+ * ipx_concat_sizes: totals[4] = read bytes, window bytes, jobs, windows; returns 1 when every table has a mask_len.  ipx_concat_tables fills
+ * caller-allocated arrays (read_off / ref_off with one entry more than jobs / windows): jobs in table order, windows renumbered; IPX_OK or
+ * IPX_ERR_ARG.  Replaces nothing in the reference: it is what makes one call per MANY loci cheap where the reference makes one per read
+ * (localn.pyx:47-66). */
+int ipx_concat_sizes(const int64_t *desc, int64_t n_tables, int64_t *totals);
+int ipx_concat_tables(const int64_t *desc, int64_t n_tables, int8_t *reads, int64_t *read_off, int8_t *refs, int64_t *ref_off, int32_t *ref_id,
+                      uint8_t *gap_open, uint8_t *gap_ext, int32_t *mask_len);
 /* host-side helper: FNV-1a (32 bit) of every job's BAM-encoded CIGAR ops, 2166136261 for a job without CIGAR (whole batches are
  * compared op for op with the reference through these, and record digests are built on them) */
 void ipx_cigar_hashes(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, uint32_t *out);

@@ -99,46 +99,43 @@ class JobTable:
         fc = np.concatenate(f) if f and fo[-1] else np.zeros(0, np.int8)
         return cls(rc, ro, fc, fo, ref_id, gap_open, gap_ext)
 
+    def desc(self):
+        """(addresses of reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len or 0, n_jobs, n_refs): what the library's
+        ipx_concat_tables takes per table.  Cached (the arrays are owned by the table and never reallocated)."""
+        d = getattr(self, "_desc", None)
+        if d is None:
+            d = self._desc = (self.reads.ctypes.data, self.read_off.ctypes.data, self.refs.ctypes.data, self.ref_off.ctypes.data,
+                              self.ref_id.ctypes.data, self.gap_open.ctypes.data, self.gap_ext.ctypes.data,
+                              0 if self.mask_len is None else self.mask_len.ctypes.data, len(self.ref_id), len(self.ref_off) - 1)
+        return d
+
     @classmethod
     def concat(cls, tables):
         """Many job tables as ONE (the many-loci entry: a locus' few hundred jobs are far too few to fill a GPU, a thousand loci are
-        not): jobs in table order, windows renumbered.  Per table only list appends; the offsets are fixed up with one vectorised
-        add per field, so ten thousand loci cost milliseconds.  mask_len: kept when every table has it, else the default rule."""
-        tables = list(tables)
-        if not tables:
-            return cls(np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int32), 0, 0)
-        # ONE Python pass over the tables (attribute reads and list appends only); everything else is whole-array arithmetic
-        ro, fo, rid, go, ge, rd, rf, mk = [], [], [], [], [], [], [], []
-        for t in tables:
-            ro.append(t.read_off); fo.append(t.ref_off); rid.append(t.ref_id); go.append(t.gap_open)
-            ge.append(t.gap_ext); rd.append(t.reads); rf.append(t.refs); mk.append(t.mask_len)
+        not): jobs in table order, windows renumbered.  r04: the copying is the library's (ipx_concat_tables: one memcpy per array and
+        table); Python only gathers ten integers per table (JobTable.desc, cached on the table) -- r03's pure-numpy form spent 39 ms
+        on the list handling of 12 500 tables.  mask_len: kept when every table has it, else the default rule."""
+        import itertools
+        tables = tables if isinstance(tables, (list, tuple)) else list(tables)
         n = len(tables)
-
-        def offsets(parts, payload):
-            """concatenated offset arrays (each starts at 0) -> one offset array; the payload arrays cut to what the offsets cover"""
-            cnt = np.fromiter(map(len, parts), np.int64, n)              # entries + 1 per table
-            allo = np.concatenate(parts)
-            ends = np.cumsum(cnt)
-            size = allo[ends - 1]                                        # bytes per table
-            base = np.cumsum(size) - size
-            keep = np.ones(len(allo), bool)
-            keep[ends - cnt] = False                                     # every table's leading 0
-            out = np.empty(len(allo) - n + 1, np.int64)
-            out[0] = 0
-            np.add(allo[keep], np.repeat(base, cnt - 1), out=out[1:])
-            have = np.fromiter(map(len, payload), np.int64, n)
-            if not np.array_equal(have, size):                           # (arrays longer than their offsets say: cut them)
-                payload = [a[:k] for a, k in zip(payload, size.tolist())]
-            return out, np.concatenate(payload), cnt - 1
-
-        read_off, reads, nj = offsets(ro, rd)
-        ref_off, refs, nr = offsets(fo, rf)
-        ref_id = np.concatenate(rid)
-        if ref_id.dtype != np.int32:
-            ref_id = ref_id.astype(np.int32)
-        ref_id = ref_id + np.repeat((np.cumsum(nr) - nr).astype(np.int32), nj)
-        mask = np.concatenate(mk) if all(m is not None for m in mk) else None
-        return cls(reads, read_off, refs, ref_off, ref_id, np.concatenate(go), np.concatenate(ge), mask)
+        if not n:
+            return cls(np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int32), 0, 0)
+        L = _lib.lib()
+        desc = np.fromiter(itertools.chain.from_iterable([t.desc() for t in tables]), np.int64, 10 * n)
+        tot = np.zeros(4, np.int64)
+        all_mask = L.ipx_concat_sizes(desc.ctypes.data, n, tot.ctypes.data)
+        rb, fb, nj, nr = (int(x) for x in tot)
+        reads, read_off = np.empty(rb, np.int8), np.empty(nj + 1, np.int64)
+        refs, ref_off = np.empty(fb, np.int8), np.empty(nr + 1, np.int64)
+        ref_id, go, ge = np.empty(nj, np.int32), np.empty(nj, np.uint8), np.empty(nj, np.uint8)
+        mask = np.empty(nj, np.int32) if all_mask else None
+        rc = L.ipx_concat_tables(desc.ctypes.data, n, reads.ctypes.data, read_off.ctypes.data, refs.ctypes.data, ref_off.ctypes.data,
+                                 ref_id.ctypes.data, go.ctypes.data, ge.ctypes.data, None if mask is None else mask.ctypes.data)
+        if rc != 0:
+            raise IpxError("ipx_concat_tables: %s" % L.ipx_last_error().decode())
+        out = cls(reads, read_off, refs, ref_off, ref_id, go, ge, mask)
+        out.table_jobs = desc[8::10].copy()                         # jobs per input table (BatchResult.split takes it)
+        return out
 
     def shard(self, lo, hi):
         """Contiguous job range [lo, hi) with only the windows it references."""
@@ -190,6 +187,31 @@ def record_digest(rec, cigar_hash):
     return int(_lib.lib().ipx_record_digest(rec.ctypes.data, ch.ctypes.data, len(rec)))
 
 
+class _SplitResults:
+    """list-like: the per-table BatchResults of BatchResult.split"""
+
+    def __init__(self, whole, counts):
+        self._whole = whole
+        c = np.asarray(counts, np.int64)
+        self._off = np.zeros(len(c) + 1, np.int64)
+        np.cumsum(c, out=self._off[1:])
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return BatchResult(self._whole.records[int(self._off[k]):int(self._off[k + 1])], self._whole.cigar_pool)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
 class BatchResult:
     """Result records (numpy structured array, RESULT_DTYPE) + the cigar pool."""
 
@@ -206,12 +228,9 @@ class BatchResult:
 
     def split(self, counts):
         """the results of a concatenated job table (JobTable.concat) back as one BatchResult per table: record views that share
-        the cigar pool (cigar_off stays an index into it)"""
-        out, at = [], 0
-        for n in counts:
-            out.append(BatchResult(self.records[at:at + int(n)], self.cigar_pool))
-            at += int(n)
-        return out
+        the cigar pool (cigar_off stays an index into it).  A sequence that makes the views when they are asked for (r04: building
+        12 500 result objects up front was a tenth of a many-loci call)."""
+        return _SplitResults(self, counts)
 
     def cigar_ops(self, i):
         r = self.records[i]
@@ -729,4 +748,5 @@ def align_loci(tables, match_score=2, mismatch_penalty=2, device=0, aligner=None
         from .sswpy import _gpu
         aligner = _gpu(device)
         aligner.set_scoring(matrix=dna_score_matrix(match_score, mismatch_penalty), flag=1, score_size=2)
-    return aligner.align(JobTable.concat(tables)).split([t.n_jobs for t in tables])
+    table = JobTable.concat(tables)
+    return aligner.align(table).split(table.table_jobs if len(tables) else [])

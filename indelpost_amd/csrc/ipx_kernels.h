@@ -1314,10 +1314,14 @@ IPX_KERNEL_WAVE_OCC(((PERM && REV) || VL2) ? ipx_dp_perm_waves(SMAX) : 1) void k
 // IpxPlan p, ...) as its first two arguments, so the callee reads them where they already are: the kernel-argument segment, through a
 // wave-uniform pointer (scalar loads, no private memory).
 #define IPX_KERNARG_AS __attribute__((address_space(4)))
-#define IPX_CALLEE_DESC_PARAMS
-#define IPX_CALLEE_DESC_ARGS
+// (the KERNEL takes the address of its argument segment and hands it down: the intrinsic is a kernel's own, in a called function it
+//  returned null on the box -- a memory fault in the first r04 attempt; made wave-uniform again in the callee so that the loads are scalar)
+#define IPX_CALLEE_DESC_PARAMS const IPX_KERNARG_AS char *ka_in_,
+#define IPX_CALLEE_DESC_ARGS ((const IPX_KERNARG_AS char *)__builtin_amdgcn_kernarg_segment_ptr()),
 #define IPX_CALLEE_DESC_LOCALS                                                                                                      \
-    const IPX_KERNARG_AS char *ka_ = (const IPX_KERNARG_AS char *)__builtin_amdgcn_kernarg_segment_ptr();                              \
+    const uint64_t kau_ = (uint64_t)ka_in_;                                                                                          \
+    const IPX_KERNARG_AS char *ka_ = (const IPX_KERNARG_AS char *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kau_ >> 32)) << 32) | \
+                                                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kau_));       \
     const IpxBatch &b = *(const IpxBatch *)ka_;                        /* (the compiler infers the constant address space back) */    \
     const IpxPlan &p = *(const IpxPlan *)(ka_ + ((sizeof(IpxBatch) + alignof(IpxPlan) - 1) & ~(alignof(IpxPlan) - 1)));
 #endif

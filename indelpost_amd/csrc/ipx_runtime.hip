@@ -678,6 +678,53 @@ int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out)
     return IPX_OK;
 }
 
+// ---- many loci as one batch (r04): the host-side concatenation of per-locus job tables ---------------------------------------------
+// desc: n_tables x 10 int64 -- addresses of a table's reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len (0: none), then
+// its n_jobs and n_refs (indelpost_amd.batch.JobTable.desc).  ipx_concat_sizes: totals[4] = read bytes, window bytes, jobs, windows, and
+// whether every table has a mask_len (return value 1) -- the caller allocates; ipx_concat_tables fills: jobs in table order, windows
+// renumbered, offsets rebased.  Plain memcpy per table: 12 500 loci of 96 jobs take ~2 ms where numpy's list handling took 39.
+int ipx_concat_sizes(const int64_t *desc, int64_t n_tables, int64_t *totals)
+{
+    int64_t rb = 0, fb = 0, nj = 0, nr = 0;
+    int all_mask = n_tables > 0;
+    for (int64_t t = 0; t < n_tables; ++t) {
+        const int64_t *d = desc + 10 * t;
+        const int64_t *ro = (const int64_t *)d[1], *fo = (const int64_t *)d[3];
+        rb += ro[d[8]] - ro[0]; fb += fo[d[9]] - fo[0]; nj += d[8]; nr += d[9];
+        if (!d[7]) all_mask = 0;
+    }
+    totals[0] = rb; totals[1] = fb; totals[2] = nj; totals[3] = nr;
+    return all_mask;
+}
+int ipx_concat_tables(const int64_t *desc, int64_t n_tables, int8_t *reads, int64_t *read_off, int8_t *refs, int64_t *ref_off, int32_t *ref_id,
+                      uint8_t *gap_open, uint8_t *gap_ext, int32_t *mask_len)
+{
+    int64_t rb = 0, fb = 0, nj = 0, nr = 0;
+    read_off[0] = 0; ref_off[0] = 0;
+    for (int64_t t = 0; t < n_tables; ++t) {
+        const int64_t *d = desc + 10 * t;
+        const int64_t n = d[8], m = d[9];
+        const int64_t *ro = (const int64_t *)d[1], *fo = (const int64_t *)d[3];
+        const int64_t r0 = ro[0], f0 = fo[0], rlen = ro[n] - r0, flen = fo[m] - f0;
+        if (n < 0 || m < 0 || rlen < 0 || flen < 0) { set_err("ipx_concat_tables: table %lld has negative sizes", (long long)t); return IPX_ERR_ARG; }
+        memcpy(reads + rb, (const int8_t *)d[0] + r0, (size_t)rlen);
+        memcpy(refs + fb, (const int8_t *)d[2] + f0, (size_t)flen);
+        for (int64_t k = 1; k <= n; ++k) read_off[nj + k] = ro[k] - r0 + rb;
+        for (int64_t k = 1; k <= m; ++k) ref_off[nr + k] = fo[k] - f0 + fb;
+        const int32_t *rid = (const int32_t *)d[4];
+        for (int64_t k = 0; k < n; ++k) {
+            if (rid[k] < 0 || rid[k] >= m) { set_err("ipx_concat_tables: table %lld, job %lld: ref_id %d out of range", (long long)t, (long long)k, rid[k]); return IPX_ERR_ARG; }
+            ref_id[nj + k] = rid[k] + (int32_t)nr;
+        }
+        memcpy(gap_open + nj, (const uint8_t *)d[5], (size_t)n);
+        memcpy(gap_ext + nj, (const uint8_t *)d[6], (size_t)n);
+        if (mask_len && d[7]) memcpy(mask_len + nj, (const int32_t *)d[7], 4 * (size_t)n);
+        rb += rlen; fb += flen; nj += n; nr += m;
+        if (nr >= (1ll << 31)) { set_err("ipx_concat_tables: more than 2^31 windows"); return IPX_ERR_ARG; }
+    }
+    return IPX_OK;
+}
+
 // ---- synthetic workload generator, host side ----------------------------------------
 static inline uint32_t xs_next(uint64_t &s)
 {
