@@ -60,7 +60,7 @@ def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
         t_cat = t_all = 0.0
         for _ in range(steps):
             t0 = time.perf_counter()
-            table = JobTable.concat(loci)
+            table = JobTable.concat(loci, staging=g.loci_staging)
             t1 = time.perf_counter()
             parts = g.align(table).split(table.table_jobs)
             t2 = time.perf_counter()

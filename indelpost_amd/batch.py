@@ -110,11 +110,14 @@ class JobTable:
         return d
 
     @classmethod
-    def concat(cls, tables):
+    def concat(cls, tables, staging=None):
         """Many job tables as ONE (the many-loci entry: a locus' few hundred jobs are far too few to fill a GPU, a thousand loci are
-        not): jobs in table order, windows renumbered.  r04: the copying is the library's (ipx_concat_tables: one memcpy per array and
-        table); Python only gathers ten integers per table (JobTable.desc, cached on the table) -- r03's pure-numpy form spent 39 ms
-        on the list handling of 12 500 tables.  mask_len: kept when every table has it, else the default rule."""
+        not): jobs in table order, windows renumbered.  r04: the copying is the library's (ipx_concat_tables: memcpy per array and
+        table, several threads); Python only gathers ten integers per table (JobTable.desc, cached on the table) -- r03's pure-numpy
+        form spent 39 ms on the list handling of 12 500 tables.  mask_len: kept when every table has it, else the default rule.
+        staging: a callable (read_bytes, window_bytes, jobs, windows, with_mask) -> the eight arrays to fill (reads, read_off, refs,
+        ref_off, ref_id, gap_open, gap_ext, mask_len or None), e.g. an aligner's page-locked, reused buffers
+        (MultiStreamAligner.loci_staging); default: fresh arrays."""
         import itertools
         tables = tables if isinstance(tables, (list, tuple)) else list(tables)
         n = len(tables)
@@ -125,10 +128,13 @@ class JobTable:
         tot = np.zeros(4, np.int64)
         all_mask = L.ipx_concat_sizes(desc.ctypes.data, n, tot.ctypes.data)
         rb, fb, nj, nr = (int(x) for x in tot)
-        reads, read_off = np.empty(rb, np.int8), np.empty(nj + 1, np.int64)
-        refs, ref_off = np.empty(fb, np.int8), np.empty(nr + 1, np.int64)
-        ref_id, go, ge = np.empty(nj, np.int32), np.empty(nj, np.uint8), np.empty(nj, np.uint8)
-        mask = np.empty(nj, np.int32) if all_mask else None
+        if staging is not None:
+            reads, read_off, refs, ref_off, ref_id, go, ge, mask = staging(rb, fb, nj, nr, bool(all_mask))
+        else:
+            reads, read_off = np.empty(rb, np.int8), np.empty(nj + 1, np.int64)
+            refs, ref_off = np.empty(fb, np.int8), np.empty(nr + 1, np.int64)
+            ref_id, go, ge = np.empty(nj, np.int32), np.empty(nj, np.uint8), np.empty(nj, np.uint8)
+            mask = np.empty(nj, np.int32) if all_mask else None
         rc = L.ipx_concat_tables(desc.ctypes.data, n, reads.ctypes.data, read_off.ctypes.data, refs.ctypes.data, ref_off.ctypes.data,
                                  ref_id.ctypes.data, go.ctypes.data, ge.ctypes.data, None if mask is None else mask.ctypes.data)
         if rc != 0:
@@ -531,7 +537,36 @@ class MultiStreamAligner:
             p.set_async_io(True)
         return True
 
+    def loci_staging(self, rb, fb, nj, nr, with_mask, cigar_ops_per_job=16):
+        """Page-locked, REUSED input and output buffers for a stream of concatenated job tables (align_loci): JobTable.concat writes
+        straight into them, the slices' copies in and out are asynchronous, and nothing is allocated or registered per batch once the
+        buffers have grown to the largest batch seen (+25 %).  Returns the eight input arrays cut to the sizes asked for.  Same
+        lifetime rule for results as pin_host."""
+        L = getattr(self.parts[0], "_L", None)
+        if L is None or not hasattr(L, "ipx_pin_host"):
+            return (np.empty(rb, np.int8), np.empty(nj + 1, np.int64), np.empty(fb, np.int8), np.empty(nr + 1, np.int64), np.empty(nj, np.int32),
+                    np.empty(nj, np.uint8), np.empty(nj, np.uint8), np.empty(nj, np.int32) if with_mask else None)
+        st = getattr(self, "_loci", None)
+        need = (rb, fb, nj + 1, nr + 1)
+        if st is None or any(n > c for n, c in zip(need, st["cap"])) or (with_mask and st["mask"] is None):
+            self.unpin()
+            cap = tuple(int(n * 1.25) + 1024 for n in need)
+            st = self._loci = {"cap": cap, "reads": np.empty(cap[0], np.int8), "read_off": np.empty(cap[2], np.int64), "refs": np.empty(cap[1], np.int8),
+                               "ref_off": np.empty(cap[3], np.int64), "ref_id": np.empty(cap[2], np.int32), "go": np.empty(cap[2], np.uint8),
+                               "ge": np.empty(cap[2], np.uint8), "mask": np.empty(cap[2], np.int32) if with_mask else None}
+            k = len(self.parts)
+            out = [(np.empty(cap[2], RESULT_DTYPE), np.empty(cap[2] * cigar_ops_per_job + 1024 * k, np.uint32)) for _ in (0, 1)]
+            for a in (st["reads"], st["read_off"], st["refs"], st["ref_off"], st["ref_id"], st["go"], st["ge"], st["mask"]) + out[0] + out[1]:
+                if a is not None and a.nbytes and L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
+                    self._pinned.append(a)
+            self._out = out
+            for p in self.parts:
+                p.set_async_io(True)
+        return (st["reads"][:rb], st["read_off"][:nj + 1], st["refs"][:fb], st["ref_off"][:nr + 1], st["ref_id"][:nj], st["go"][:nj], st["ge"][:nj],
+                st["mask"][:nj] if with_mask else None)
+
     def unpin(self):
+        self._loci = None
         L = getattr(self.parts[0], "_L", None) if self.parts else None
         for a in self._pinned:
             if L is not None:
@@ -609,7 +644,7 @@ class MultiStreamAligner:
 
     def collect(self):
         jobs = self._submitted
-        if self._out is not None and len(self._out[0][0]) == jobs.n_jobs and hasattr(self._active[0], "download_async_into"):
+        if self._out is not None and len(self._out[0][0]) >= jobs.n_jobs and hasattr(self._active[0], "download_async_into"):
             got = self._align_tail_async()
             if got is not None:
                 return got
@@ -623,6 +658,7 @@ class MultiStreamAligner:
         """sync slice k, start its download into the pinned output buffers, go on to slice k+1: a slice's records travel while
         the later slices still compute.  None when something did not fit (the caller falls back to the blocking path)."""
         rec, pool = self._out[self._out_turn]
+        rec = rec[:self._submitted.n_jobs]                       # (the buffers may be larger than this batch: loci_staging)
         self._out_turn ^= 1
         lo = pb = 0
         try:
@@ -748,5 +784,5 @@ def align_loci(tables, match_score=2, mismatch_penalty=2, device=0, aligner=None
         from .sswpy import _gpu
         aligner = _gpu(device)
         aligner.set_scoring(matrix=dna_score_matrix(match_score, mismatch_penalty), flag=1, score_size=2)
-    table = JobTable.concat(tables)
+    table = JobTable.concat(tables, staging=getattr(aligner, "loci_staging", None))
     return aligner.align(table).split(table.table_jobs if len(tables) else [])

@@ -1751,27 +1751,6 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
     }
 }
 
-// (tier kernels) the tile body as a CALL: inlined, the bodies of a tier share one register allocation and the longest one's spills
-// land in all of them; called, each keeps the allocation of its stand-alone kernel (the batch and plan descriptors travel by
-// reference, i.e. through private memory -- they are read in the tile's set-up and finalisation only, never in the column loop)
-template <int SMAX, bool REV, int BH>
-IPX_NOINLINE_DEV void dp_skew_tile_call(IPX_CALLEE_DESC_PARAMS const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
-                                        unsigned char *lds, const uint32_t nz)
-{
-    IPX_CALLEE_DESC_LOCALS
-    dp_skew_tile<SMAX, REV, BH>(b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
-}
-// (tier kernels) the tile body of class c, c a compile-time-unrollable value in [SLO / STEP, SHI / STEP]
-template <int SLO, int SHI, bool REV, int BH>
-IPX_DEV void dp_skew_tile_at(int c, const IpxBatch &b, const IpxPlan &p, uint32_t first, int cnt, int pass, uint32_t *maxcol, bool mc_lds, unsigned char *lds, uint32_t nz)
-{
-    constexpr int STEP = BH ? 2 : 1;
-    if constexpr (SLO <= SHI) {
-        if (c == SLO / STEP) dp_skew_tile_call<SLO, REV, BH>(IPX_CALLEE_DESC_ARGS first, cnt, pass, maxcol, mc_lds, lds, nz);
-        else dp_skew_tile_at<SLO + STEP, SHI, REV, BH>(c, b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
-    }
-}
-
 // prologue shared by the wavefront kernels: the score table in LDS (offset 0: [6 window letters][4 read letters], the high byte of each score
 // as a half, looked up by byte offset = letter x 4), this block's column maxima, the lane-0 mask
 #define IPX_SKEW_PROLOGUE                                                                                                             \
@@ -1810,38 +1789,10 @@ IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBa
     }
 }
 
-// Several classes in ONE launch (r03).  A class launch that fills less than one round of wave slots lasts as long as its longest tile
-// whatever its size, and the kernels of a stream run one after the other: with five read-length classes per pass and a quarter of a
-// million jobs per stream, config 4 spent a third of every stream's time in the tails of launches the other streams could not fill
-// (the same table at twice the size ran 22 % faster per job).  A tier kernel holds the tile bodies of segLen SLO..SHI -- classes of one
-// occupancy -- and walks the tiles of the launch's classes in one grid: one ramp and one tail per tier instead of one per class.
-// set_mask: bit (class - cls_base) = the class is served by this launch (cls_base = SLO for the 16-bit passes, SLO / 2 in the 8-bit dialect).
-// waves per SIMD a tier asks for: what its longest class's stand-alone kernel runs at
-IPX_HD constexpr int ipx_tier_waves(int shi) { return shi <= 12 ? 4 : shi <= 25 ? 3 : 2; }
-template <int SLO, int SHI, bool REV, int BH = 0>
-IPX_KERNEL_WAVE_OCC(ipx_tier_waves(SHI)) void k_dp_skew_tier(IpxBatch b, IpxPlan p, uint32_t set_mask, int maxcols, int pass)
-{
-    constexpr int STEP = BH ? 2 : 1, C0 = SLO / STEP, C1 = SHI / STEP;             // classes of the tier
-    static_assert(SLO % STEP == 0 && SHI % STEP == 0 && C1 - C0 < 32, "tier bounds");
-    constexpr int W = 8;
-    IPX_SKEW_PROLOGUE
-    int own_cls = C0;                                                 // class reached by the walk
-    uint32_t own_base = 0;                                            // owned tiles in the classes before own_cls
-    for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
-        for (; own_cls <= C1; ++own_cls) {
-            const uint32_t n = ((set_mask >> (own_cls - C0)) & 1u) ? p.tile_off[own_cls + 1] - p.tile_off[own_cls] : 0u;
-            if (want < own_base + n) break;
-            own_base += n;
-        }
-        if (own_cls > C1) break;
-        const int cls = (int)xl_first((uint32_t)own_cls);
-        const uint32_t first = p.cls_off[cls] + (want - own_base) * NA;
-        const uint32_t avail = p.cls_off[cls + 1] - first;
-        const int cnt = avail < (uint32_t)NA ? (int)avail : NA;
-        dp_skew_tile_at<SLO, SHI, REV, BH>(cls, b, p, first, cnt, pass, maxcol, mc_lds, lds, nz);
-    }
-}
-
+// (r03 had k_dp_skew_tier here: the tile bodies of one occupancy tier's classes as CALLS from one launch.  r04 took it out: every call
+//  spilled the callee-saved half of the body's registers to scratch -- 288-368 bytes per lane, a quarter of a gigabyte per launch, what the
+//  r03 profile showed as WRITE_SIZE -- and with the launches sized from the previous run's tile counts the per-class launches are as fast:
+//  config 4 55.8 with the tiers, 56.3 without; config 5 72.7 / 73.5.)
 #if IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
 // k_dp_long<W, REV>: sw_sse2_byte (W = 16, ssw.c:197-384) / sw_sse2_word (W = 8, ssw.c:410-586) for reads too long for the
@@ -3616,12 +3567,6 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_LAT_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_LAT_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_DP_UNIT_X(X) IPX_LAT_FAMILY(X, false, 0) IPX_LAT_FAMILY(X, true, 0) IPX_LAT_FAMILY(X, false, 2) IPX_LAT_FAMILY(X, true, 2)
-// tier kernels: several classes of one occupancy in one launch
-#define IPX_TIER_SIG (IpxBatch, IpxPlan, uint32_t, int, int)
-#define IPX_TIER_WORD(X, REV) X(1, 12, REV, 0) X(13, 19, REV, 0) X(20, 25, REV, 0) X(26, 32, REV, 0)
-#define IPX_TIER_BYTE(X, REV) X(2, 12, REV, 2) X(14, 24, REV, 2) X(26, 32, REV, 2)
-#define IPX_TIER_DEFINE(LO, HI, REV, BH) template __global__ void k_dp_skew_tier<LO, HI, REV, BH> IPX_TIER_SIG;
-#define IPX_TIER_EXTERN(LO, HI, REV, BH) extern template __global__ void k_dp_skew_tier<LO, HI, REV, BH> IPX_TIER_SIG;
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 // the stepped 8-bit passes of classes 1..16 in one launch (k_dp_pass_tier)
@@ -3632,7 +3577,6 @@ IPX_DP_UNIT_X(IPX_LAT_EXTERN)
 IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
 IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 1) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 2) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, true, 2)
-IPX_TIER_WORD(IPX_TIER_EXTERN, false) IPX_TIER_WORD(IPX_TIER_EXTERN, true) IPX_TIER_BYTE(IPX_TIER_EXTERN, false) IPX_TIER_BYTE(IPX_TIER_EXTERN, true)
 IPX_DP_UNIT_I(IPX_DP_EXTERN_H) IPX_DP_UNIT_J(IPX_DP_EXTERN_H) IPX_DP_UNIT_M(IPX_DP_EXTERN_H) IPX_VL2_FAMILY(IPX_VL2_EXTERN)
 IPX_DP_UNIT_A(IPX_DP_EXTERN) IPX_DP_UNIT_B(IPX_DP_EXTERN) IPX_DP_UNIT_C(IPX_DP_EXTERN) IPX_DP_UNIT_D(IPX_DP_EXTERN)
 IPX_DP_UNIT_E(IPX_DP_EXTERN) IPX_DP_UNIT_F(IPX_DP_EXTERN) IPX_DP_UNIT_G(IPX_DP_EXTERN) IPX_DP_UNIT_H(IPX_DP_EXTERN)

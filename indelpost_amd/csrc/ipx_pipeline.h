@@ -278,7 +278,7 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
 // Wavefront launches of a pass whose (fast-gap) classes were planned by ipx_plan_classes.  BH = 0: 16-bit passes, class c = c segments.
 // BH = 1 / 2: the plain recurrence in the 8-bit dialect, class c (8-bit segLen) = 2c segments of the 8-lane layout.  A launch also serves
 // the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).  The classes of `set` that fall into one occupancy
-// tier share ONE launch (k_dp_skew_tier) when there are at least two of them; a class alone in its tier keeps its own kernel.
+// (r03's shared tier launches, k_dp_skew_tier, are gone: see ipx_kernels.h.)
 template <class BE, bool REV, int BH>
 static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing, bool lat = false)
 {
@@ -304,30 +304,6 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
     const int pflag = pass | (ipx_dp_mc_in_lds(8, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
     uint8_t todo[IPX_MAX_EXACT + 1];
     for (int c = 0; c <= IPX_MAX_EXACT; ++c) todo[c] = c <= (BH ? 16 : IPX_MAX_EXACT) ? set[c] : 0;
-    if (BH != 1 && !(routing & IPX_ROUTE_NO_TIERS)) {
-        // tiers in SEGMENTS (the template arguments of k_dp_skew_tier); classes are segments (BH = 0) or segments / 2
-        static const int word_tiers[4][2] = {{1, 12}, {13, 19}, {20, 25}, {26, 32}}, byte_tiers[3][2] = {{2, 12}, {14, 24}, {26, 32}};
-        const int nt = BH ? 3 : 4, step = BH ? 2 : 1;
-        for (int t = 0; t < nt; ++t) {
-            const int c0 = (BH ? byte_tiers[t][0] : word_tiers[t][0]) / step, c1 = (BH ? byte_tiers[t][1] : word_tiers[t][1]) / step;
-            uint32_t mask = 0;
-            int n = 0;
-            for (int c = c0; c <= c1; ++c) if (todo[c]) { mask |= 1u << (c - c0); ++n; }
-            if (n < 2) continue;
-            for (int c = c0; c <= c1; ++c) todo[c] = 0;
-            const int key = IPX_KEY(kclass, IPX_SUB_TIER + t);
-            be.note_dp_set(key, pass, c0, mask, 16);
-            for (int c = c0; c <= c1; ++c) if ((mask >> (c - c0)) & 1u) be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
-            const int grid = be.dp_grid_set(pass, c0, mask);
-#define IPX_TIER_CASE(T, LO, HI) case T: be.launch(key, k_dp_skew_tier<LO, HI, REV, BH>, grid, 64, lds, b, p, mask, maxcols, pflag); break;
-            if constexpr (BH == 0) {
-                switch (t) { IPX_TIER_CASE(0, 1, 12) IPX_TIER_CASE(1, 13, 19) IPX_TIER_CASE(2, 20, 25) IPX_TIER_CASE(3, 26, 32) default: break; }
-            } else if constexpr (BH == 2) {
-                switch (t) { IPX_TIER_CASE(0, 2, 12) IPX_TIER_CASE(1, 14, 24) IPX_TIER_CASE(2, 26, 32) default: break; }
-            }
-#undef IPX_TIER_CASE
-        }
-    }
     for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
         if (!todo[c]) continue;
         be.note_dp(IPX_KEY(kclass, c), pass, c, 16);

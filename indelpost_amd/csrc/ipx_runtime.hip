@@ -9,6 +9,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/indelpost_hip.h"
@@ -699,29 +700,60 @@ int ipx_concat_sizes(const int64_t *desc, int64_t n_tables, int64_t *totals)
 int ipx_concat_tables(const int64_t *desc, int64_t n_tables, int8_t *reads, int64_t *read_off, int8_t *refs, int64_t *ref_off, int32_t *ref_id,
                       uint8_t *gap_open, uint8_t *gap_ext, int32_t *mask_len)
 {
+    // pass 1 (serial): where every table's jobs, windows and letters start in the outputs
+    std::vector<int64_t> at(4 * ((size_t)n_tables + 1));
     int64_t rb = 0, fb = 0, nj = 0, nr = 0;
-    read_off[0] = 0; ref_off[0] = 0;
     for (int64_t t = 0; t < n_tables; ++t) {
         const int64_t *d = desc + 10 * t;
         const int64_t n = d[8], m = d[9];
         const int64_t *ro = (const int64_t *)d[1], *fo = (const int64_t *)d[3];
-        const int64_t r0 = ro[0], f0 = fo[0], rlen = ro[n] - r0, flen = fo[m] - f0;
-        if (n < 0 || m < 0 || rlen < 0 || flen < 0) { set_err("ipx_concat_tables: table %lld has negative sizes", (long long)t); return IPX_ERR_ARG; }
-        memcpy(reads + rb, (const int8_t *)d[0] + r0, (size_t)rlen);
-        memcpy(refs + fb, (const int8_t *)d[2] + f0, (size_t)flen);
-        for (int64_t k = 1; k <= n; ++k) read_off[nj + k] = ro[k] - r0 + rb;
-        for (int64_t k = 1; k <= m; ++k) ref_off[nr + k] = fo[k] - f0 + fb;
-        const int32_t *rid = (const int32_t *)d[4];
-        for (int64_t k = 0; k < n; ++k) {
-            if (rid[k] < 0 || rid[k] >= m) { set_err("ipx_concat_tables: table %lld, job %lld: ref_id %d out of range", (long long)t, (long long)k, rid[k]); return IPX_ERR_ARG; }
-            ref_id[nj + k] = rid[k] + (int32_t)nr;
-        }
-        memcpy(gap_open + nj, (const uint8_t *)d[5], (size_t)n);
-        memcpy(gap_ext + nj, (const uint8_t *)d[6], (size_t)n);
-        if (mask_len && d[7]) memcpy(mask_len + nj, (const int32_t *)d[7], 4 * (size_t)n);
-        rb += rlen; fb += flen; nj += n; nr += m;
+        if (n < 0 || m < 0 || ro[n] < ro[0] || fo[m] < fo[0]) { set_err("ipx_concat_tables: table %lld has negative sizes", (long long)t); return IPX_ERR_ARG; }
+        at[4 * t] = rb; at[4 * t + 1] = fb; at[4 * t + 2] = nj; at[4 * t + 3] = nr;
+        rb += ro[n] - ro[0]; fb += fo[m] - fo[0]; nj += n; nr += m;
         if (nr >= (1ll << 31)) { set_err("ipx_concat_tables: more than 2^31 windows"); return IPX_ERR_ARG; }
     }
+    read_off[0] = 0; ref_off[0] = 0;
+    // pass 2: the copies, a contiguous range of tables per thread (a quarter of a gigabyte per million jobs: one core's memcpy was most
+    // of a many-loci call)
+    std::mutex bad_mu;
+    int64_t bad_t = -1, bad_k = -1; int bad_v = 0;
+    auto work = [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t) {
+            const int64_t *d = desc + 10 * t;
+            const int64_t n = d[8], m = d[9];
+            const int64_t *ro = (const int64_t *)d[1], *fo = (const int64_t *)d[3];
+            const int64_t r0 = ro[0], f0 = fo[0], orb = at[4 * t], ofb = at[4 * t + 1], onj = at[4 * t + 2], onr = at[4 * t + 3];
+            memcpy(reads + orb, (const int8_t *)d[0] + r0, (size_t)(ro[n] - r0));
+            memcpy(refs + ofb, (const int8_t *)d[2] + f0, (size_t)(fo[m] - f0));
+            for (int64_t k = 1; k <= n; ++k) read_off[onj + k] = ro[k] - r0 + orb;
+            for (int64_t k = 1; k <= m; ++k) ref_off[onr + k] = fo[k] - f0 + ofb;
+            const int32_t *rid = (const int32_t *)d[4];
+            for (int64_t k = 0; k < n; ++k) {
+                if (rid[k] < 0 || rid[k] >= m) { std::lock_guard<std::mutex> g(bad_mu); if (bad_t < 0) { bad_t = t; bad_k = k; bad_v = rid[k]; } break; }
+                ref_id[onj + k] = rid[k] + (int32_t)onr;
+            }
+            memcpy(gap_open + onj, (const uint8_t *)d[5], (size_t)n);
+            memcpy(gap_ext + onj, (const uint8_t *)d[6], (size_t)n);
+            if (mask_len && d[7]) memcpy(mask_len + onj, (const int32_t *)d[7], 4 * (size_t)n);
+        }
+    };
+    int nth = (int)std::thread::hardware_concurrency();
+    if (nth > 8) nth = 8;
+    if (nth < 1 || rb + fb < (8ll << 20)) nth = 1;               // (small: a thread costs more than it copies)
+    if (nth == 1) work(0, n_tables);
+    else {
+        std::vector<std::thread> th;
+        int64_t t0 = 0;
+        for (int q = 0; q < nth; ++q) {                            // equal BYTES per thread, not equal table counts
+            const int64_t want = (rb + fb) * (q + 1) / nth;
+            int64_t t1 = t0;
+            while (t1 < n_tables && (q == nth - 1 || at[4 * t1] + at[4 * t1 + 1] < want)) ++t1;
+            th.emplace_back(work, t0, t1);
+            t0 = t1;
+        }
+        for (auto &x : th) x.join();
+    }
+    if (bad_t >= 0) { set_err("ipx_concat_tables: table %lld, job %lld: ref_id %d out of range", (long long)bad_t, (long long)bad_k, bad_v); return IPX_ERR_ARG; }
     return IPX_OK;
 }
 

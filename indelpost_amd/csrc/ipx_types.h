@@ -83,7 +83,7 @@ enum {
                                    //   lanes per GPU lane (16 reads per wave)
     IPX_ROUTE_NO_PLAIN_FIRST = 256,  // 8-bit passes in the r02 bracket order (lower bound, upper bound, stepped) instead of plain recurrence + proof
     IPX_ROUTE_NO_CLASS_MERGE = 512,  // every segLen class keeps its own wavefront launch (no rare class served by a longer class's kernel)
-    IPX_ROUTE_NO_TIERS = 1024,       // one wavefront launch per class even where several classes of one occupancy could share a launch (k_dp_skew_tier)
+    IPX_ROUTE_NO_TIERS = 1024,       // one launch per class of the stepped 8-bit passes too (no k_dp_pass_tier).  (r03: also the wavefront passes' tier launches, gone in r04)
     IPX_ROUTE_NO_EXACT_DIRECT = 2048, // a read the proofs leave open takes the lower-bound stage before the stepped one (r03 first half) instead of
                                       //   the stepped pass at once (which steps only where a cut can happen and costs little more than the lower bound)
     IPX_ROUTE_TB_NO_WAVE_PER_JOB = 4096,  // small batches too take the lane-per-job traceback kernels (default: up to 2048 jobs, one wave per job)

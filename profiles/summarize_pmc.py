@@ -55,7 +55,7 @@ def bench_name(k):
         else:
             base = "dp_word_rev" if rev else "dp_word_fwd"
         return "%s_%s" % (base, ("s%d" % s) if exact else "long")
-    m = re.match(r"void k_dp_skew<(\d+), (true|false)(?:, (\d+|true|false))?>", k)
+    m = re.match(r"void k_dp_skew<(\d+), (true|false)(?:, (\d+|true|false))?(?:, (\d+))?>", k)     # (r04: a fourth argument, lanes per read: 8, or 32 = the latency tier)
     if m:
         bh = {"true": 1, "false": 0, None: 0}.get(m.group(3), None)
         bh = int(m.group(3)) if bh is None else bh
@@ -68,12 +68,18 @@ def bench_name(k):
     m = re.match(r"void k_tb_fast<(\d+)>", k)
     if m:
         return "traceback_fast_bw%s" % m.group(1)
-    for a, b in (("k_tb_coop", "traceback_tier1"), ("k_plan", "plan"), ("k_tb_list", "tb_list"),
+    m = re.match(r"void k_tb_diag<(\d+)>", k)
+    if m:
+        return "traceback_diag%s" % m.group(1)
+    for a, b in (("k_tb_coop", "traceback_coop"), ("k_plan", "plan"), ("k_tb_list", "tb_list"),
                  ("k_prove_overflow", "prove_overflow"), ("k_init", "init"), ("void k_prove_plain<false>", "prove_plain_fwd"),
                  ("void k_prove_plain<true>", "prove_plain_rev")):
         if k.startswith(a):
             return b
     return k.split("(")[0]
+
+
+SOURCE_TAG = {}          # filled by __main__: tag and the fingerprint of the kernel sources the profile was taken on
 
 
 def merge_json(name, workload, data):
@@ -82,6 +88,8 @@ def merge_json(name, workload, data):
         cur = json.load(open(path))
     except (OSError, ValueError):
         cur = {}
+    data = dict(data)
+    data.update(SOURCE_TAG)   # bench.py quotes these figures only while the kernel sources still have this fingerprint
     cur[workload] = data
     json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
 
@@ -155,6 +163,13 @@ def one(root, tag, w):
 
 if __name__ == "__main__":
     root, tag = sys.argv[1], sys.argv[2]
+    try:                                                   # written on the GPU box by tools/profile_round.sh, from the sources that were profiled
+        sha = open(os.path.join(root, "kernel_source_sha16.txt")).read().strip()
+    except OSError:
+        sys.path.insert(0, os.path.dirname(HERE))
+        import bench
+        sha = bench.kernel_source_sha16()
+    SOURCE_TAG.update({"_tag": tag, "_kernel_source_sha16": sha})
     for w in sys.argv[3:]:
         one(root, tag, w)
     bl = bench_line(os.path.join(root, "bench.log"))

@@ -371,7 +371,8 @@ def test_emu_half_precision_and_wavefront_forms_of_the_16_bit_passes(emu, oracle
 def test_emu_rare_classes_ride_along_and_tiers_share_a_launch(emu, oracle_mod, port):
     """r03: (1) a segLen class with few reads is listed under the next populated class and served by that class's wavefront
     kernel with its rows shifted down (IpxBatch::cls_map, k_dp_skew ROW SHIFT) -- forward and reverse, 16-bit and plain 8-bit;
-    (2) the classes of one occupancy tier share ONE launch (k_dp_skew_tier).  Same records with either switched off, equal to
+    (2) the classes of the stepped 8-bit passes share ONE launch (k_dp_pass_tier; the wavefront passes' tier launches of r03 are
+    gone in r04).  Same records with either switched off, equal to
     the oracle; empty reads and reads that end before their window does are in the mix (their reverse prefix is much shorter
     than the read: a class of its own, decided on the device)."""
     rng = np.random.default_rng(99)
@@ -412,11 +413,11 @@ def test_emu_rare_classes_ride_along_and_tiers_share_a_launch(emu, oracle_mod, p
         tier = lambda a, kc: [k % 256 for k in a.launches if k // 256 == kc and k % 256 >= 150 and k % 256 < 160]
         if ms == 3:
             # 16-bit forward first: classes 13 (100 + the 104s), 17 (131), 19, 32 (250 + 201) ... rare ones merged away; 13..19 share tier 1
-            assert tier(a0, K_WORD_FIRST) and not tier(a1, K_WORD_FIRST)
+            assert not tier(a0, K_WORD_FIRST) and not tier(a1, K_WORD_FIRST)
             assert len(_launched(a1, K_WORD_FIRST)) < len(_launched(a2, K_WORD_FIRST))        # merged classes: fewer launches
             assert not [c for c in _launched(a1, K_WORD_REV) if c == 140]                   # no branch-guarded sweep launch left for the reverse pass
         else:
-            assert tier(a0, K_BYTE_PLAIN) and not tier(a1, K_BYTE_PLAIN)
+            assert not tier(a0, K_BYTE_PLAIN) and not tier(a1, K_BYTE_PLAIN)
             assert (base.records["mode"] == 0).all()
             # the stepped 8-bit passes (what the proofs leave open, slow gaps aside): ONE launch for the classes 1..16 (k_dp_pass_tier,
             # timing sub-key 158) instead of one per class; stand-alone launches again with the tiers switched off

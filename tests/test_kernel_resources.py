@@ -12,14 +12,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 BUDGET = {  # kernel name prefix: (max registers, max spilled registers)
-    "k_dp_skew<19, false, 0>": (168, 0),        # headline forward pass: three waves per SIMD
-    "k_dp_skew<19, true, 0>": (168, 0),
-    "k_dp_skew<13, false, 0>": (128, 0),        # four waves
-    "k_dp_skew<20, false, 2>": (168, 0),        # plain 8-bit recurrence of 150 bp reads
-    "k_dp_skew<25, false, 0>": (168, 40),       # three waves at the price of a few spills
-    "k_dp_skew<32, false, 0>": (256, 0),
-    "k_dp_skew_tier<13, 19, false, 0>": (168, 8),
-    "k_dp_skew_tier<13, 19, true, 0>": (168, 8),
+    "k_dp_skew<19, false, 0, 8>": (168, 0),        # headline forward pass: three waves per SIMD
+    "k_dp_skew<19, true, 0, 8>": (168, 0),
+    "k_dp_skew<13, false, 0, 8>": (128, 0),        # four waves
+    "k_dp_skew<20, false, 2, 8>": (168, 0),        # plain 8-bit recurrence of 150 bp reads
+    "k_dp_skew<25, false, 0, 8>": (168, 40),       # three waves at the price of a few spills
+    "k_dp_skew<32, false, 0, 8>": (256, 0),
+    "k_dp_skew<5, false, 0, 32>": (128, 0),     # r04 latency tier: 150 bp reads at 32 lanes per read
+    "k_dp_skew<5, true, 0, 32>": (128, 0),
+    "k_tb_diag<16>": (128, 0),                  # r04 anti-diagonal traceback tiers
+    "k_tb_diag<32>": (128, 0),
+    "k_tb_diag<64>": (128, 0),
+    "k_prove_overflow_diag": (64, 0),
     "k_prove_plain<false>": (168, 0),
     "k_prove_plain<true>": (128, 0),
     "k_prove_overflow": (128, 0),

@@ -7,6 +7,9 @@ export TMPDIR=/tmp
 D=gpurun_out/${1:-prof}
 WL=${2:-"2b 2a 4"}
 mkdir -p $D
+python3 -c "import bench; print(bench.kernel_source_sha16())" > $D/kernel_source_sha16.txt
+# what a VALU instruction costs (refreshed every round): whole-launch time of ncu*4*W one-wave blocks of 96 000 independent instructions each
+(./tools/ubench_issue | grep "^#" | awk '{ printf "%s  -> %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n", $0, $9 * 1e-3 * 2.4e9 / ($11 * $5) }') > $D/valu_issue_ubench.txt 2>&1 || true
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $D/bench.log 2> $D/bench.err; echo "bench rc=$?"
 for w in $WL; do
   B="python3 bench.py --workload $w --no-subconfigs --no-cpu-baseline --no-single-stream"
