@@ -44,21 +44,24 @@ def run_end_to_end(ip, jobs, scoring, dev, streams, steps, depth=None):
 
 
 def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
-    """The many-loci entry (indelpost_amd.align_loci) on the config-5 shape: `n_loci` loci, each its own JobTable of 16 reads x 6
-    gap-penalty pairs with per-read windows (what retarget_jobs builds per locus), handed over as a LIST per step.  Timed per
-    step: JobTable.concat + upload + pipeline + download + BatchResult.split -- host memory to host memory, everything a caller
-    of grid_search_many pays below its own Python."""
+    """The many-loci entry on the config-5 shape: `n_loci` loci, each its own JobTable of 16 reads x 6 gap-penalty pairs with per-read
+    windows (what retarget_jobs builds per locus), handed over as a LIST per step, host memory to host memory: concatenation (the
+    library's ipx_concat_tables into page-locked, reused staging buffers) + H2D + pipeline + D2H + a split back into per-locus results.
+    `value`: a STREAM of such lists through two aligners in rotation (while one batch computes, the next list is concatenated into the
+    other aligner's staging) -- what a caller working through a VCF gets; `one_list_at_a_time`: indelpost_amd.align_loci called list by
+    list, nothing overlapped -- the latency of one such call."""
     from indelpost_amd import synth
     from indelpost_amd.batch import JobTable, align_loci
     jobs = synth.config5_jobs(n_loci=n_loci)
     per = jobs.n_jobs // n_loci
     loci = [jobs.shard(k * per, (k + 1) * per) for k in range(n_loci)]          # outside the timed region: the caller's own tables
-    g = ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams)
+    ring = [ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams) for _ in (0, 1)]
     try:
+        g = ring[0]
         for _ in range(2):
             parts = align_loci(loci, aligner=g)
         t_cat = t_all = 0.0
-        for _ in range(steps):
+        for _ in range(steps):                                     # one list at a time
             t0 = time.perf_counter()
             table = JobTable.concat(loci, staging=g.loci_staging)
             t1 = time.perf_counter()
@@ -67,15 +70,32 @@ def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
             t_cat += t1 - t0
             t_all += t2 - t0
         whole = ip.BatchResult(np.concatenate([p.records for p in parts]), parts[0].cigar_pool)
-        dt = t_all / steps
-        return {"value": round(jobs.n_jobs / dt / 1e6, 4), "unit": "million alignments/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-                "n_loci": n_loci, "jobs_per_locus": per, "n_jobs": jobs.n_jobs, "concat_ms_per_step": round(t_cat / steps * 1e3, 3),
-                "digest": whole.digest(), "sum_score1": int(whole.records["score1"].astype(np.int64).sum()),
-                "note": "host memory to host memory through align_loci (concat + H2D + pipeline + D2H + split); compare with configs.5, "
-                        "the same jobs resident in HBM.  The per-locus tables are the caller's (made outside the timed region, their ten-integer "
-                        "descriptors cached by the warm-up calls: a table handed over for the first time costs ~8 us more)"}
+        digest, sum1 = whole.digest(), int(whole.records["score1"].astype(np.int64).sum())
+        dt1 = t_all / steps
+        # a stream of lists: two aligners in rotation
+        align_loci(loci, aligner=ring[1])
+        tabs = [None, None]
+        last = None
+        t0 = time.perf_counter()
+        for k in range(steps + 1):
+            if k < steps:
+                a = ring[k % 2]
+                tabs[k % 2] = JobTable.concat(loci, staging=a.loci_staging)
+                a.submit(tabs[k % 2])
+            if k >= 1:
+                last = ring[(k - 1) % 2].collect().split(tabs[(k - 1) % 2].table_jobs)
+        dt2 = (time.perf_counter() - t0) / steps
+        assert ip.BatchResult(np.concatenate([p.records for p in last]), last[0].cigar_pool).digest() == digest
+        return {"value": round(jobs.n_jobs / dt2 / 1e6, 4), "unit": "million alignments/s", "ms_per_step": round(dt2 * 1e3, 3), "steps": steps,
+                "n_loci": n_loci, "jobs_per_locus": per, "n_jobs": jobs.n_jobs, "aligners_in_rotation": 2,
+                "one_list_at_a_time": {"value": round(jobs.n_jobs / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 3), "concat_ms_per_step": round(t_cat / steps * 1e3, 3)},
+                "digest": digest, "sum_score1": sum1,
+                "note": "host memory to host memory (concat + H2D + pipeline + D2H + split); compare with configs.5, the same jobs resident "
+                        "in HBM.  The per-locus tables are the caller's (made outside the timed region, their ten-integer descriptors cached by "
+                        "the warm-up calls: a table handed over for the first time costs ~8 us more)"}
     finally:
-        g.close()
+        for a in ring:
+            a.close()
 
 
 def config4_chunk(rank, windows_per_gpu=1250):

@@ -6,9 +6,13 @@ sys.path.insert(0, ".")
 import indelpost_amd as ip
 from indelpost_amd import synth
 
-for rl in (100, 125, 150, 200, 250):
+routing = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # e.g. 262144 = ROUTE_NO_W16: the long classes at 8 lanes per read
+lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 125, 150, 200, 250]
+for rl in lens:
     jobs = synth.config2_jobs(1_000_000, 3, 1, rl, 400)
     g = ip.MultiStreamAligner(0, 3, 2, streams=4)
+    if routing:
+        g.set_routing(routing)
     g.upload(jobs)
     for _ in range(2):
         g.run()
