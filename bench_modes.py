@@ -76,18 +76,26 @@ def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
         align_loci(loci, aligner=ring[1])
         tabs = [None, None]
         last = None
+        ph = {"concat": 0.0, "submit": 0.0, "collect": 0.0}
         t0 = time.perf_counter()
         for k in range(steps + 1):
             if k < steps:
                 a = ring[k % 2]
+                ta = time.perf_counter()
                 tabs[k % 2] = JobTable.concat(loci, staging=a.loci_staging)
+                tb = time.perf_counter()
                 a.submit(tabs[k % 2])
+                tc = time.perf_counter()
+                ph["concat"] += tb - ta; ph["submit"] += tc - tb
             if k >= 1:
+                ta = time.perf_counter()
                 last = ring[(k - 1) % 2].collect().split(tabs[(k - 1) % 2].table_jobs)
+                ph["collect"] += time.perf_counter() - ta
         dt2 = (time.perf_counter() - t0) / steps
         assert ip.BatchResult(np.concatenate([p.records for p in last]), last[0].cigar_pool).digest() == digest
         return {"value": round(jobs.n_jobs / dt2 / 1e6, 4), "unit": "million alignments/s", "ms_per_step": round(dt2 * 1e3, 3), "steps": steps,
                 "n_loci": n_loci, "jobs_per_locus": per, "n_jobs": jobs.n_jobs, "aligners_in_rotation": 2,
+                "host_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in ph.items()},
                 "one_list_at_a_time": {"value": round(jobs.n_jobs / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 3), "concat_ms_per_step": round(t_cat / steps * 1e3, 3)},
                 "digest": digest, "sum_score1": sum1,
                 "note": "host memory to host memory (concat + H2D + pipeline + D2H + split); compare with configs.5, the same jobs resident "
@@ -96,6 +104,48 @@ def run_many_loci(ip, scoring, dev, streams, steps, n_loci=12500):
     finally:
         for a in ring:
             a.close()
+
+
+def run_full_configs(ip, dev, streams, steps, warmup):
+    """BASELINE configs[3] and configs[4] at their FULL sizes on one GPU: 10 tables of 996 k mixed-length jobs (9.96 M) and 8 tables of
+    1.2 M per-read-window x penalty-grid jobs (9.6 M), table k generated from seed SEED + 977 k, each run under the headline's protocol
+    (inputs resident, warm-up, `steps` timed steps) and each digest-checked against the reference's results for THAT table
+    (tests/golden/bench_digests.json: "4", "4#1".."4#9", "5", "5#1".."5#7", oracle/gen_bench_digests.py)."""
+    from bench import WORKLOADS, make_jobs, golden_digest
+    out = {"mode": "full-configs", "steps": steps, "warmup": warmup, "streams": streams, "configs": {}}
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench_digests.json")))["workloads"]
+    for name, ntab in (("4", 10), ("5", 8)):
+        scoring, desc = WORKLOADS[name]
+        g = ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams)
+        tabs, jobs_total, t_total = [], 0, 0.0
+        try:
+            for k in range(ntab):
+                jobs = make_jobs(name, 0, k)
+                g.upload(jobs)
+                for _ in range(warmup):
+                    g.run()
+                g.sync()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    g.run()
+                g.sync()
+                dt = (time.perf_counter() - t0) / steps
+                res = g.download()
+                key = name if k == 0 else "%s#%d" % (name, k)
+                want = gold.get(key, {})
+                d = res.digest()
+                ok = want.get("n_jobs") == jobs.n_jobs and want.get("digest") == d
+                assert ok, "table %s: digest %d differs from the reference's %r" % (key, d, want.get("digest"))
+                tabs.append({"table": key, "n_jobs": jobs.n_jobs, "value": round(jobs.n_jobs / dt / 1e6, 4), "ms_per_step": round(dt * 1e3, 4),
+                             "digest": d, "digest_matches_reference": True})
+                jobs_total += jobs.n_jobs
+                t_total += dt
+        finally:
+            g.close()
+        out["configs"][name] = {"workload": desc.format(n=jobs_total) + " -- %d tables" % ntab, "jobs_total": jobs_total,
+                                "value": round(jobs_total / t_total / 1e6, 4), "unit": "million alignments/s",
+                                "ms_for_all_tables": round(t_total * 1e3, 3), "tables": tabs}
+    return out
 
 
 def config4_chunk(rank, windows_per_gpu=1250):

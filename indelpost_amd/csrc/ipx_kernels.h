@@ -1787,14 +1787,15 @@ IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : W == 16 ? 3 : 1) void k
 {
     IPX_SKEW_PROLOGUE
     static_assert(TILE % NA == 0, "a planner tile is a whole number of the kernel's tiles");
+    // (a planner tile of TILE jobs is TILE / NA of the kernel's tiles, each a block's work of its own: short-lived blocks interleave the streams' kernels)
+    constexpr uint32_t PER = TILE / NA;
     for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
-        if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
-        const uint32_t first = p.cls_off[cls] + want * TILE;
+        const uint32_t tile = want / PER, sub = (want % PER) * NA;
+        if (p.tile_off[cls] + tile >= p.tile_off[cls + 1]) break;
+        const uint32_t first = p.cls_off[cls] + tile * TILE;
         const uint32_t avail = p.cls_off[cls + 1] - first;
-        const int cnt = avail < (uint32_t)TILE ? (int)avail : TILE;
-        IPX_NOUNROLL
-        for (int sub = 0; sub < TILE; sub += NA)
-            if (cnt > sub) dp_skew_tile<SMAX, REV, BH, W>(b, p, first + (uint32_t)sub, cnt - sub < NA ? cnt - sub : NA, pass, maxcol, mc_lds, lds, nz);
+        const uint32_t cnt = avail < (uint32_t)TILE ? avail : (uint32_t)TILE;
+        if (cnt > sub) dp_skew_tile<SMAX, REV, BH, W>(b, p, first + sub, (int)(cnt - sub < (uint32_t)NA ? cnt - sub : (uint32_t)NA), pass, maxcol, mc_lds, lds, nz);
     }
 }
 

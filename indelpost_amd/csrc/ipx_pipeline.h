@@ -314,7 +314,7 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
             if constexpr ((C) >= 1 && (C) <= 16)                                                                               \
                 be.launch(IPX_KEY(kclass, c), k_dp_skew<2 * (C), REV, BH>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); \
         } else if ((C) >= 26 && !(routing & IPX_ROUTE_NO_W16))     /* the long classes at 16 lanes per read: three waves per SIMD */            \
-            be.launch(IPX_KEY(kclass, c), k_dp_skew<((C) >= 26 ? ((C) + 1) / 2 : 13), REV, 0, 16, 16>, be.dp_grid(pass, c), 64,                 \
+            be.launch(IPX_KEY(kclass, c), k_dp_skew<((C) >= 26 ? ((C) + 1) / 2 : 13), REV, 0, 16, 16>, 2 * be.dp_grid(pass, c), 64,             \
                       ipx_dp_lds_bytes(16, 0, REV, maxcols, true, routing), b, p, c, maxcols,                                                   \
                       pass | (ipx_dp_mc_in_lds(16, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0));                                       \
         else be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), REV, 0>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag);     \

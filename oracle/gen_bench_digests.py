@@ -27,6 +27,12 @@ def workloads():
     yield "4", (3, 2), synth.config4_jobs()
     yield "5", (3, 2), synth.config5_jobs()
     yield "4x1250", (3, 2), synth.config4_jobs(n_windows=1250)      # chunk 0 of bench.py --sharded (1250 windows per GPU)
+    # BASELINE's full sizes on one GPU (bench.py --full-configs): configs[3] = 10 tables of 996 k jobs, configs[4] = 8 tables of 1.2 M jobs,
+    # table k generated from seed SEED + 977 k (k = 0 is the table above)
+    for k in range(1, 10):
+        yield "4#%d" % k, (3, 2), synth.config4_jobs(seed=synth.SEED + 977 * k)
+    for k in range(1, 8):
+        yield "5#%d" % k, (3, 2), synth.config5_jobs(seed=synth.SEED + 977 * k)
 
 
 def main():
@@ -34,8 +40,14 @@ def main():
     assert O.have_reference(), "needs oracle/_ref/libssw_ref.so (run `make -C oracle`)"
     be = O.Backend("reference")
     cores = len(os.sched_getaffinity(0))
+    path = os.path.join(ROOT, "tests", "golden", "bench_digests.json")
     out = {"generator": "oracle/gen_bench_digests.py", "checker": "reference ssw.c (oracle/_ref/libssw_ref.so)", "workloads": {}}
+    only_missing = "--missing" in sys.argv                      # keep what the file already has (the reference has not changed)
+    if only_missing and os.path.exists(path):
+        out = json.load(open(path))
     for name, scoring, jobs in workloads():
+        if only_missing and name in out["workloads"]:
+            continue
         rec = O.cpu_batch_results(be, jobs, O.dna_matrix(*scoring), cores)
         assert (rec["is_null"] == 0).all()
         out["workloads"][name] = {
@@ -44,7 +56,7 @@ def main():
             "sum_cigar_len": int(rec["cigar_len"].astype(np.int64).sum()), "flag_nonzero": int((rec["flag"] != 0).sum()),
             "flag1": int((rec["flag"] == 1).sum())}
         print(name, out["workloads"][name], flush=True)
-    with open(os.path.join(ROOT, "tests", "golden", "bench_digests.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")
 
