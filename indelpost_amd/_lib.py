@@ -15,9 +15,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libindelpost_hip.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
 SRC = os.path.join(CSRC, "ipx_runtime.hip")
-# the library is several translation units (compiled in parallel): the runtime + every other kernel, and twenty-one
+# the library is several translation units (compiled in parallel): the runtime + every other kernel, and twenty
 # units holding the explicit instantiations of the striped-DP kernel families (csrc/ipx_kernels.h, end of file)
-UNITS = [SRC] + [os.path.join(CSRC, "ipx_dp_%s.hip" % u) for u in "abcdefghijklmnopqvwxy"]
+UNITS = [SRC] + [os.path.join(CSRC, "ipx_dp_%s.hip" % u) for u in "abcdefghijklmnopqvwx"]
 HEADERS = [os.path.join(CSRC, h) for h in ("ipx_simt.h", "ipx_types.h", "ipx_kernels.h", "ipx_pipeline.h")] + [
     os.path.join(os.path.dirname(PKG_DIR), "include", "indelpost_hip.h")]
 BUILD_DIR = os.path.join(CSRC, "build")

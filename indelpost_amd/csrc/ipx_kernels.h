@@ -1420,7 +1420,7 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
 {
     static_assert(!(BH == 1 && REV), "the upper-bound stage of the bracket is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
-    static_assert(W == 8 || W == 16 || W == 32 || W == 64, "8 lanes per read (16 reads per wave), 16 for the longest classes, or the latency tier's 32 / 64");
+    static_assert(W == 8 || W == 32 || W == 64, "8 lanes per read (16 reads per wave), or the latency tier's 32 / 64");
     constexpr int G = 64 / W, S = SMAX;
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
@@ -1777,25 +1777,19 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
 // 307 x 205 instructions per tile.  Four reads per wave; the lane-to-lane hand-over is a whole-wavefront DPP shift (wave_shr:1) instead
 // of a row shift; the per-read reductions of the finalisation add two ds_bpermute steps.  Same recurrence, same outputs (ROW SHIFT serves
 // any read whose padded row count fits).
-// 16 = the LONG classes of a big batch (r04: 26..32 segments at 8 lanes, reads of 201..256 bp): at 8 lanes per read their H, E, saved column and
-// selectors are 4 x 32 registers -- two waves per SIMD, 77 % of the issue ceiling (r03) because two waves do not hide the
-// per-step LDS look-up and lane hand-over.  At 16 lanes per read the same rows are 13..16 segments (~150 registers, three waves, no spills) for
-// ~7 % more instructions per read (the step's bookkeeping is shared by 8 reads instead of 16) and 15 instead of 7 steps of lead-in.  The
-// pass's tiles hold 16 jobs (a pass has ONE tile size): the kernel takes a tile as two half-tiles of 8 (TILE = 16).
-template <int SMAX, bool REV, int BH = 0, int W = 8, int TILE = 128 / W>
-IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : W == 16 ? 3 : 1) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
+// (16 lanes per read for the LONG classes of a big batch -- 26..32 segments at 8 lanes are 4 x 32 state registers, two waves per SIMD, 77 % of
+//  the issue ceiling -- was built and measured in r04: 13..16 segments, ~145 registers, three waves, no spills; the forward kernel of 250 bp
+//  reads took 10.4 instead of 12.2 ms per million, and the BATCH got slower (250 bp alone: 35.4 against 36.8 M aln/s; config 4: 54.6-55.2
+//  against 55.0-55.6): three resident DP waves per SIMD leave the other streams' latency-bound kernels even less room.  Taken out again.)
+template <int SMAX, bool REV, int BH = 0, int W = 8>
+IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBatch b, IpxPlan p, int cls, int maxcols, int pass)
 {
     IPX_SKEW_PROLOGUE
-    static_assert(TILE % NA == 0, "a planner tile is a whole number of the kernel's tiles");
-    // (a planner tile of TILE jobs is TILE / NA of the kernel's tiles, each a block's work of its own: short-lived blocks interleave the streams' kernels)
-    constexpr uint32_t PER = TILE / NA;
     for (uint32_t want = (uint32_t)IPX_BID;; want += (uint32_t)IPX_GDIM) {
-        const uint32_t tile = want / PER, sub = (want % PER) * NA;
-        if (p.tile_off[cls] + tile >= p.tile_off[cls + 1]) break;
-        const uint32_t first = p.cls_off[cls] + tile * TILE;
+        if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
+        const uint32_t first = p.cls_off[cls] + want * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;
-        const uint32_t cnt = avail < (uint32_t)TILE ? avail : (uint32_t)TILE;
-        if (cnt > sub) dp_skew_tile<SMAX, REV, BH, W>(b, p, first + sub, (int)(cnt - sub < (uint32_t)NA ? cnt - sub : (uint32_t)NA), pass, maxcol, mc_lds, lds, nz);
+        dp_skew_tile<SMAX, REV, BH, W>(b, p, first, avail < (uint32_t)NA ? (int)avail : NA, pass, maxcol, mc_lds, lds, nz);
     }
 }
 
@@ -3577,11 +3571,6 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_LAT_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_LAT_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_DP_UNIT_X(X) IPX_LAT_FAMILY(X, false, 0) IPX_LAT_FAMILY(X, true, 0) IPX_LAT_FAMILY(X, false, 2) IPX_LAT_FAMILY(X, true, 2)
-// the long classes of a big batch at 16 lanes per read: 13..16 segments, tiles of 16 jobs
-#define IPX_W16_FAMILY(X, REV) X(13, REV) X(14, REV) X(15, REV) X(16, REV)
-#define IPX_W16_DEFINE(S, REV) template __global__ void k_dp_skew<S, REV, 0, 16, 16>(IpxBatch, IpxPlan, int, int, int);
-#define IPX_W16_EXTERN(S, REV) extern template __global__ void k_dp_skew<S, REV, 0, 16, 16>(IpxBatch, IpxPlan, int, int, int);
-#define IPX_DP_UNIT_Y(X) IPX_W16_FAMILY(X, false) IPX_W16_FAMILY(X, true)
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)
 // the stepped 8-bit passes of classes 1..16 in one launch (k_dp_pass_tier)
@@ -3589,7 +3578,6 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_PASS_TIER_EXTERN(REV) extern template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #if defined(IPX_EXTERN_KERNELS)
 IPX_DP_UNIT_X(IPX_LAT_EXTERN)
-IPX_DP_UNIT_Y(IPX_W16_EXTERN)
 IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)
 IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 1) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, false, 2) IPX_SKEW_BH_FAMILY(IPX_SKEW_BH_EXTERN, true, 2)

@@ -313,11 +313,7 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
         if constexpr (BH != 0) {                                                                                               \
             if constexpr ((C) >= 1 && (C) <= 16)                                                                               \
                 be.launch(IPX_KEY(kclass, c), k_dp_skew<2 * (C), REV, BH>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); \
-        } else if ((C) >= 26 && !(routing & IPX_ROUTE_NO_W16))     /* the long classes at 16 lanes per read: three waves per SIMD */            \
-            be.launch(IPX_KEY(kclass, c), k_dp_skew<((C) >= 26 ? ((C) + 1) / 2 : 13), REV, 0, 16, 16>, 2 * be.dp_grid(pass, c), 64,             \
-                      ipx_dp_lds_bytes(16, 0, REV, maxcols, true, routing), b, p, c, maxcols,                                                   \
-                      pass | (ipx_dp_mc_in_lds(16, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0));                                       \
-        else be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), REV, 0>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag);     \
+        } else be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), REV, 0>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag);     \
         break;
         switch (c) {
             IPX_SK_CASE(0) IPX_SK_CASE(1) IPX_SK_CASE(2) IPX_SK_CASE(3) IPX_SK_CASE(4) IPX_SK_CASE(5) IPX_SK_CASE(6) IPX_SK_CASE(7) IPX_SK_CASE(8)

@@ -91,7 +91,6 @@ enum {
     IPX_ROUTE_TB_NO_DIAG = 16384,         // no anti-diagonal traceback tiers (k_tb_diag): bands wider than 7, doubled bands and small batches take one wave per job (k_tb_coop) as in r03
     IPX_ROUTE_NO_LAT = 32768,             // small batches too take the 8-lanes-per-read wavefront kernels (no latency tier: k_dp_skew W = 32)
     IPX_ROUTE_NO_LAT_PROOF = 131072,      // the latency tier keeps the lane-per-read overflow proof (k_prove_overflow) instead of k_prove_overflow_diag
-    IPX_ROUTE_NO_W16 = 262144,            // the longest classes (26..32 segments) too at 8 lanes per read (two waves per SIMD) instead of 16 lanes (three)
     IPX_ROUTE_FORCE_LAT = 65536,          // (testing) the latency tier whatever the batch size, where its other conditions hold
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };

@@ -400,7 +400,7 @@ def test_emu_rare_classes_ride_along_and_tiers_share_a_launch(emu, oracle_mod, p
     for ms, mm in ((3, 2), (1, 1)):
         mat = oracle_mod.dna_matrix(ms, mm)
         out = {}
-        for routing in (0, R.ROUTE_NO_TIERS, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_CLASS_MERGE | R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_NO_W16):   # (r04: the 250 / 201 bp reads take the 16-lanes-per-read kernels unless NO_W16)
+        for routing in (0, R.ROUTE_NO_TIERS, R.ROUTE_NO_CLASS_MERGE, R.ROUTE_NO_CLASS_MERGE | R.ROUTE_NO_PLAIN_FIRST):
             a = emu(0, ms, mm)
             a.set_routing(routing)
             out[routing] = (a, a.align(jobs))

@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import indelpost_amd as ip
 from indelpost_amd import synth
 
-routing = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # e.g. 262144 = ROUTE_NO_W16: the long classes at 8 lanes per read
+routing = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # library routing switches (indelpost_amd.batch.ROUTE_*)
 lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 125, 150, 200, 250]
 for rl in lens:
     jobs = synth.config2_jobs(1_000_000, 3, 1, rl, 400)
