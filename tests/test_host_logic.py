@@ -291,13 +291,16 @@ def test_pinned_output_bookkeeping_of_the_multi_stream_aligner(emu):
     got_b = m.align(b)                                                   # the other output pair: got_a stays valid
     for got, plain in ((got_a, plain_a), (got_b, plain_b)):
         assert all(got.as_dict(i) == plain.as_dict(i) for i in range(10))
-    assert got_a.records is m._out[0][0] and got_b.records is m._out[1][0]
+    assert np.shares_memory(got_a.records, m._out[0][0]) and np.shares_memory(got_b.records, m._out[1][0])     # (views: the buffers may be larger than a batch, loci_staging)
     assert got_a.records["cigar_off"][5] >= 1024                         # second slice: rebased into its region of the pool
     kept = got_a.copy()
     m.align(b)                                                           # third collect: overwrites the first pair ...
     assert all(kept.as_dict(i) == plain_a.as_dict(i) for i in range(10))   # ... the copy is unaffected
     m._out = [(np.zeros(10, RESULT_DTYPE), np.zeros(1500, np.uint32)) for _ in (0, 1)]   # room for one slice's region only
     small = m.align(a)                                                   # falls back to the blocking download
+    m._out = [(np.zeros(25, RESULT_DTYPE), np.zeros(8192, np.uint32)) for _ in (0, 1)]   # buffers LARGER than the batch (reused staging): views of the first 10 records
+    big = m.align(a)
+    assert len(big.records) == 10 and np.shares_memory(big.records, m._out[0][0]) and all(big.as_dict(i) == plain_a.as_dict(i) for i in range(10))
     assert all(small.as_dict(i) == plain_a.as_dict(i) for i in range(10)) and small.records is not m._out[0][0]
     m.close()
 
