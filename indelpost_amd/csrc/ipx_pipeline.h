@@ -101,6 +101,8 @@ static inline bool ipx_dp_mc_in_lds(int W, bool rev, int maxcols, bool perm, int
 static inline int ipx_dp_lds_bytes(int W, int SMAX, bool rev, int maxcols, bool perm, int routing)
 {
     const int mc = ipx_dp_mc_in_lds(W, rev, maxcols, perm, routing) ? (64 / W) * maxcols * 4 : 0;
+    // (r04 experiment, not kept: reserving 20 KB here caps the DP kernels at two waves per SIMD so that the other streams' latency-bound kernels
+    //  find register room beside them -- config 4 55.4 -> 49.1 M aln/s, 2b 85 -> 72: the DP kernels need their three waves more)
     return (perm ? 64 : 640 * (SMAX > 0 ? SMAX : 1)) + 64 + mc;
 }
 

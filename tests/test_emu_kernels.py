@@ -531,7 +531,7 @@ def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
     refs[3][rng.integers(0, 333, 20)] = 4
     reads, rid, go, ge = [], [], [], []
     gaps = [(3, 1), (3, 0), (5, 1), (4, 0), (2, 1), (10, 1), (255, 1)]
-    for i in range(90):
+    for i in range(64):
         k = int(rng.integers(0, len(refs)))
         w = refs[k]
         L = int(rng.integers(1, 257)) if i % 7 else (1, 7, 8, 9, 31, 32, 33, 64, 65, 128, 255, 256, 0)[(i // 7) % 13]
@@ -557,7 +557,7 @@ def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
         mat = oracle_mod.dna_matrix(*scoring)
         exp = [port.align(r, refs[rid[i]], mat, go[i], ge[i]) for i, r in enumerate(reads)]
         got = {}
-        for routing in (R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT_PROOF):
+        for routing in ((R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT_PROOF, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST) if scoring == (3, 2) else (R.ROUTE_FORCE_LAT,)):
             a = emu(0, *scoring)
             a.set_routing(routing)
             res = a.align(jobs)

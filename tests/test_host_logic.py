@@ -325,3 +325,43 @@ def test_record_digest_is_xxh64(hip_lib):
             m[:, k] = rec[f]
         m[:, 9] = ch
         assert record_digest(rec, ch) == xxhash.xxh64(np.ascontiguousarray(m, "<i8").tobytes()).intdigest(), n
+
+
+def test_library_concat_handles_views_masks_and_empty_tables(hip_lib):
+    """ipx_concat_tables behind JobTable.concat: tables that are VIEWS into a bigger table (offsets not starting at 0), tables with and
+    without mask_len, an empty table and a table without windows; equal to a plain numpy concatenation; a bad ref_id is refused"""
+    rng = np.random.default_rng(77)
+    refs = [rng.integers(0, 4, int(n)).astype(np.int8) for n in (40, 77, 5, 120)]
+    reads = [rng.integers(0, 5, int(rng.integers(0, 60))).astype(np.int8) for _ in range(23)]
+    big = JobTable.from_sequences(reads, refs, [i % 4 for i in range(23)], [3 + i % 5 for i in range(23)], [i % 2 for i in range(23)], encoded=True)
+    parts = [big.shard(0, 7), big.shard(7, 7), big.shard(7, 19), big.shard(19, 23),
+             JobTable(np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int32), 0, 0)]
+    # a table whose arrays are longer than its offsets say, starting at an offset of its own
+    t = big.shard(3, 9)
+    t2 = JobTable(np.concatenate([np.full(5, 9, np.int8), t.reads, np.full(3, 9, np.int8)]), t.read_off + 5, t.refs, t.ref_off, t.ref_id, t.gap_open, t.gap_ext)
+    parts.append(t2)
+    cat = JobTable.concat(parts)
+    assert cat.table_jobs.tolist() == [p.n_jobs for p in parts] and cat.mask_len is None
+    at_job = at_ref = 0
+    for p in parts:
+        for k in range(p.n_jobs):
+            lo, hi = int(p.read_off[k]), int(p.read_off[k + 1])
+            clo, chi = int(cat.read_off[at_job + k]), int(cat.read_off[at_job + k + 1])
+            assert np.array_equal(cat.reads[clo:chi], p.reads[lo:hi])
+            w, cw = int(p.ref_id[k]), int(cat.ref_id[at_job + k])
+            assert cw == w + at_ref
+            assert np.array_equal(cat.refs[int(cat.ref_off[cw]):int(cat.ref_off[cw + 1])], p.refs[int(p.ref_off[w]):int(p.ref_off[w + 1])])
+            assert cat.gap_open[at_job + k] == p.gap_open[k] and cat.gap_ext[at_job + k] == p.gap_ext[k]
+        at_job += p.n_jobs
+        at_ref += p.n_refs
+    assert cat.n_jobs == at_job and cat.n_refs == at_ref and cat.read_off[-1] == len(cat.reads) and cat.ref_off[-1] == len(cat.refs)
+    # mask_len survives only when every table has it
+    m1 = JobTable(parts[0].reads, parts[0].read_off, parts[0].refs, parts[0].ref_off, parts[0].ref_id, parts[0].gap_open, parts[0].gap_ext, np.arange(7, dtype=np.int32) + 15)
+    m2 = JobTable(parts[3].reads, parts[3].read_off, parts[3].refs, parts[3].ref_off, parts[3].ref_id, parts[3].gap_open, parts[3].gap_ext, np.arange(4, dtype=np.int32) + 40)
+    both = JobTable.concat([m1, m2])
+    assert both.mask_len.tolist() == list(range(15, 22)) + list(range(40, 44))
+    assert JobTable.concat([m1, parts[3]]).mask_len is None
+    assert JobTable.concat([]).n_jobs == 0
+    bad = JobTable(parts[0].reads, parts[0].read_off, parts[0].refs, parts[0].ref_off, parts[0].ref_id + 50, parts[0].gap_open, parts[0].gap_ext)
+    with pytest.raises(ip.IpxError):
+        JobTable.concat([parts[3], bad])

@@ -51,3 +51,30 @@ def test_register_budgets_of_the_hot_kernels():
         assert k in seen, "kernel %s not found in the built objects" % k
         v, sp = seen[k]
         assert v <= vmax and sp <= smax, "%s: %d registers, %d spilled (budget %d / %d)" % (k, v, sp, vmax, smax)
+
+
+def test_called_tier_bodies_find_the_descriptors_where_they_read_them():
+    """k_dp_pass_tier's called bodies read IpxBatch / IpxPlan from the kernel-argument segment at offset 0 and align_up(sizeof(IpxBatch), 8)
+    (csrc/ipx_kernels.h IPX_CALLEE_DESC_LOCALS): the code object's argument table must say the same"""
+    import subprocess
+    import kernel_regs
+    obj = os.path.join(ROOT, "indelpost_amd", "csrc", "build", "ipx_dp_v.o")
+    if not os.path.exists(obj) or not os.path.exists(kernel_regs.LLVM + "clang-offload-bundler"):
+        pytest.skip("no built objects / no ROCm tools here")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.co")
+        subprocess.run([kernel_regs.LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(tmp, "unused.o")], check=True)
+        subprocess.run([kernel_regs.LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, stderr=subprocess.DEVNULL)
+        txt = subprocess.run([kernel_regs.LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    src = "#include <stdio.h>\n#include \"%s\"\nint main(){printf(\"%%zu %%zu\", sizeof(IpxBatch), sizeof(IpxPlan));}" % os.path.join(ROOT, "indelpost_amd", "csrc", "ipx_types.h")
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "s.cpp"), "w").write(src)
+        subprocess.run(["g++", "-o", os.path.join(tmp, "s"), os.path.join(tmp, "s.cpp")], check=True)
+        sb, sp = (int(x) for x in subprocess.run([os.path.join(tmp, "s")], capture_output=True, text=True).stdout.split())
+    import re
+    blocks = txt.split(".args:")[1:]
+    assert blocks
+    for blk in blocks:
+        offs = [(int(o), int(z)) for o, z in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)", blk)[:2]]
+        assert offs == [(0, sb), ((sb + 7) & ~7, sp)], offs
