@@ -175,6 +175,7 @@ int ipx_kernel_times(ipx_ctx *c, float *ms, int *launches);   /* arrays of ipx_n
  * counts x alignments per tile; 0 for the other classes): the "units one launch processes" of the roofline */
 int ipx_kernel_units(ipx_ctx *c, int64_t *units);
 float ipx_last_run_ms(ipx_ctx *c);            /* events around the last ipx_run, valid after ipx_sync */
+int ipx_debug_reruns(ipx_ctx *c);             /* runs ipx_sync had to repeat because a pass predicted empty (small batches: not launched) held a job (diagnostic) */
 int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out12);  /* traceback routing of the last run (diagnostic): jobs per list -- [0..6] lane-per-job kernels (band 1..7), [7] wave-per-job kernel, [8..10] anti-diagonal tiers of 16 / 32 / 64 lanes per job, [11] 0 */
 
 /* host-side helper: the CIGAR strings of a whole batch in one call, formatted as sswpy.pyx:283-289 does per

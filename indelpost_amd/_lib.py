@@ -36,7 +36,7 @@ EXPORTS = [
     "ipx_device_count", "ipx_create", "ipx_destroy", "ipx_last_error", "ipx_set_params", "ipx_set_routing", "ipx_upload",
     "ipx_run", "ipx_sync", "ipx_download", "ipx_download_async", "ipx_wait", "ipx_set_async_io", "ipx_pin_host",
     "ipx_unpin_host", "ipx_align_batch", "ipx_set_profiling",
-    "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts",
+    "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts", "ipx_debug_reruns",
     "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars", "ipx_cigar_hashes", "ipx_record_digest", "ipx_concat_sizes", "ipx_concat_tables",
 ]
 
@@ -154,6 +154,8 @@ def lib():
     L.ipx_last_run_ms.restype = C.c_float
     L.ipx_last_run_ms.argtypes = [vp]
     L.ipx_debug_tb_counts.argtypes = [vp, vp]
+    L.ipx_debug_reruns.argtypes = [vp]
+    L.ipx_debug_reruns.restype = C.c_int
     L.ipx_debug_tb_counts.restype = C.c_int
     L.ipx_synth_window.restype = C.c_uint64
     L.ipx_synth_window.argtypes = [C.c_uint64, vp, i32]

@@ -2673,7 +2673,12 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                 IpxResult r = b.res[i];
                 const bool opt = r.mode == IPX_MODE_BYTE_OPT;
                 if (opt) { r.mode = IPX_MODE_BYTE; ((volatile uint8_t *)&b.res[i].mode)[0] = IPX_MODE_BYTE; }
-                if (cigar_needed(b, r)) {
+                // every record is final by now -- unless its next pass was predicted empty and not launched (latency tier): the host repeats the run
+                // (such a record is not listed for the traceback either: its begin position is not there yet)
+                const bool stuck = (r.mode != IPX_MODE_BYTE && r.mode != IPX_MODE_WORD && r.mode != IPX_MODE_FAIL) ||
+                                   (r.mode != IPX_MODE_FAIL && rev_needed(b, r.score1) && r.read_begin1 < 0);       // (... or its reverse pass was not launched)
+                if (stuck) atomic_or_u32(b.status, IPX_STATUS_RERUN);
+                if (!stuck && cigar_needed(b, r)) {
                     const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
                     const bool exact_opt = b.gap_open[i] > b.gap_ext[i] && (r.mode == IPX_MODE_WORD || opt || r.score1 < 128);
                     const int bw = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;

@@ -364,9 +364,16 @@ static void ipx_build_static_plans(BE &be, const IpxBatch &b, const IpxWorkspace
 }
 
 template <class BE>
-static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing, bool reset_status = false)
+static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, const IpxDims &d, int routing, bool reset_status = false, bool speculate = false)
 {
     static_assert(IPX_TB_NCOUNTERS == 12, "k_init resets twelve traceback counters");
+    // SPECULATION (r04, latency tier): which passes a job takes is decided on the device, so the host launches every pass -- and in a small
+    // call the planner launch and the kernels of a pass that finds nothing cost 8 + 4.5 us of a 300 us chain, five times over.  A pass the
+    // PREVIOUS run of the context found empty (be.pass_predicted_empty: planner tile counts read back at ipx_sync) is not launched; k_tb_list,
+    // which sees every record, notices a job left behind in such a pass (IPX_STATUS_RERUN) and the caller repeats the run with every pass.
+    // Only with the traceback in the pipeline (it carries the guard) and only where the caller can repeat (`speculate`).
+    const bool spec = speculate && d.lat && (7 & b.flag) != 0 && !(routing & IPX_ROUTE_NO_SPECULATE);
+    auto skip = [&](int pass) { return spec && ((routing & IPX_ROUTE_TEST_SKIP_ALL) || be.pass_predicted_empty(pass)); };
     const int maxcols = d.max_ref_len + 4;
     uint8_t has8_all[IPX_NUM_CLASSES], has16_all[IPX_NUM_CLASSES];
     for (int c = 0; c < IPX_NUM_CLASSES; ++c) { has8_all[c] = d.has8_low[c] | d.has8_wf[c]; has16_all[c] = d.has16_low[c] | d.has16_wf[c]; }
@@ -416,19 +423,19 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             if (d.any_low) {
                 ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing, d.lat != 0);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
-                if (!b.exact_direct) {
+                if (!b.exact_direct && !skip(IPX_PASS_BYTE_LOW2)) {
                     ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
                     ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_LOW2], ws, d.has8_low, maxcols, IPX_K_BYTE_LOW2, IPX_PASS_BYTE_LOW2, routing, 1, 0, low2 ? 16 : 8);
                 }
             }
-            if (wf) {                                            // word-first reads whose overflow could not be proven (and that most likely do overflow)
+            if (wf && !skip(IPX_PASS_BYTE_CHECK)) {                // word-first reads whose overflow could not be proven (and that most likely do overflow)
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
                 ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], ws, d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing, 3, 0, low2 ? 16 : 8);
             }
         } else {
         if (d.any_low)
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], ws, d.has8_low, maxcols, IPX_K_BYTE_LOW, IPX_PASS_BYTE_FIRST, routing, 3, 0, ipx_first_na(b, d, routing));
-        if (wf) {                                                // word-first reads whose overflow could not be proven
+        if (wf && !skip(IPX_PASS_BYTE_CHECK)) {                    // word-first reads whose overflow could not be proven
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_CHECK], IPX_PASS_BYTE_CHECK, low2 ? 16 : 8);
             ipx_launch_dp<BE, 16, false, IPX_STAGE_LOW>(be, b, ws.plan[IPX_PASS_BYTE_CHECK], ws, d.has8_wf, maxcols, IPX_K_BYTE_CHECK, IPX_PASS_BYTE_CHECK, routing, 3, 0, low2 ? 16 : 8);
         }
@@ -444,10 +451,12 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         }
         }
         // reads the bounds left open: the reference's stepped lazy-F
+        if (!skip(IPX_PASS_BYTE_EXACT)) {
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_EXACT], IPX_PASS_BYTE_EXACT, 8);
         ipx_launch_dp<BE, 16, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_EXACT], ws, has8_all, maxcols, IPX_K_BYTE_EXACT, IPX_PASS_BYTE_EXACT, routing, 3, 0, 8);
+        }
     }
-    if (b.score_size != 0) {                                     // 16-bit forward pass (ssw.c:844-847, 853-855)
+    if (b.score_size != 0 && !(b.score_size == 2 && skip(IPX_PASS_WORD_FWD))) {   // 16-bit forward pass (ssw.c:844-847, 853-855)
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, ipx_skew_na(d), b.score_size == 1);
         if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, d.lat != 0);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], ws, b.score_size == 1 ? has16_all : d.has16_low, maxcols,
@@ -455,16 +464,18 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     }
     if (b.flag != 0) {                                           // begin position (ssw.c:872-886)
         if (b.score_size != 1) {
-            if (d.plain_first) {
+            if (d.plain_first && !skip(IPX_PASS_BYTE_REV_PLAIN)) {
                 // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, ipx_skew_na(d));
                 ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing, d.lat != 0);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
             }
+            if (!skip(IPX_PASS_BYTE_REV)) {
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV], IPX_PASS_BYTE_REV, 8);
             ipx_launch_dp<BE, 16, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_BYTE_REV], ws, has8_all, maxcols, IPX_K_BYTE_REV, IPX_PASS_BYTE_REV, routing, 3, 0, 8);
+            }
         }
-        if (b.score_size != 0) {
+        if (b.score_size != 0 && !skip(IPX_PASS_WORD_REV)) {
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, ipx_skew_na(d));
             if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, d.lat != 0);
             ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], ws, has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, 3, word_from, 16);

@@ -97,6 +97,8 @@ struct ipx_ctx {
     uint32_t *stats_dev = nullptr;              // ... and where the planner leaves them
     uint8_t *cls_map_dev = nullptr;             // IpxBatch::cls_map (filled from IpxDims::cls_map when the static plans are built)
     bool prev_valid = false;
+    bool speculated = false;                    // the last ipx_run left out passes predicted empty: a job found in one makes ipx_sync repeat the run
+    int reruns = 0;                             // ... how often that has happened (ipx_debug_reruns)
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
 };
 
@@ -159,6 +161,8 @@ struct HipBackend {
         return sized(t);
     }
     void note_f16(int, int) {}
+    // (latency tier) the previous run of this context planned no tile for the pass: ipx_run_pipeline may leave it out (k_tb_list guards)
+    bool pass_predicted_empty(int pass) const { return c->prev_valid && c->prev_tiles[pass * (IPX_NUM_CLASSES + 1) + IPX_NUM_CLASSES] == 0; }
     void copy_u32(uint32_t *dst, const uint32_t *src, int n)
     {
         hipError_t e = hipMemcpyAsync(dst, src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream);
@@ -273,6 +277,7 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
     c->bias = -bias;
     c->flag = flag & 255; c->filters = filters & 0xFFFF; c->filterd = filterd; c->score_size = score_size;
     c->static_valid = false;
+    c->prev_valid = false;             // (launch sizes and pass predictions learned under other parameters say nothing)
     return IPX_OK;
 }
 
@@ -281,6 +286,7 @@ int ipx_set_routing(ipx_ctx *c, int flags)
     if (!c) { set_err("ipx_set_routing: null context"); return IPX_ERR_ARG; }
     c->routing = flags;
     c->static_valid = false;
+    c->prev_valid = false;
     return IPX_OK;
 }
 
@@ -457,7 +463,7 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     return IPX_OK;
 }
 
-int ipx_run(ipx_ctx *c)
+static int ipx_run_impl(ipx_ctx *c, bool allow_speculation)
 {
     if (!c) { set_err("ipx_run: null context"); return IPX_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
@@ -493,12 +499,16 @@ int ipx_run(ipx_ctx *c)
         c->static_valid = true;
     }
     HIPCHK(hipEventRecord(c->run_start, c->stream));
-    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims, c->routing, !first_run);
+    // speculation on which passes are empty (latency tier): from the previous run of this context, also across batches of similar size
+    c->speculated = allow_speculation && c->prev_valid && c->dims.lat != 0 && (7 & c->flag) != 0 && !(c->routing & IPX_ROUTE_NO_SPECULATE);
+    if (c->n_jobs > 0) ipx_run_pipeline(be, b, c->ws, c->dims, c->routing, !first_run, c->speculated);
     ++c->runs_since_sync;
     HIPCHK(hipEventRecord(c->run_stop, c->stream));
     if (be.err != hipSuccess) { set_err("kernel launch failed: %s", hipGetErrorString(be.err)); return IPX_ERR_NO_DEVICE; }
     return IPX_OK;
 }
+
+int ipx_run(ipx_ctx *c) { return ipx_run_impl(c, true); }
 
 int ipx_sync(ipx_ctx *c)
 {
@@ -521,6 +531,16 @@ int ipx_sync(ipx_ctx *c)
     uint32_t st = 0, cur_st[8] = {0};
     // cursor (4 words) and status (4 words) are neighbours in the small-table buffer: one read-back for both
     HIPCHK(hipMemcpy(cur_st, c->batch.cigar_cursor, sizeof cur_st, hipMemcpyDeviceToHost));
+    if ((cur_st[4] & IPX_STATUS_RERUN) && c->speculated) {
+        // a job sat in a pass that was predicted empty and left out (ipx_run_pipeline, speculation): the whole run again, every pass launched
+        ++c->reruns;
+        const int rc = ipx_run_impl(c, false);
+        if (rc != IPX_OK) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipEventElapsedTime(&c->last_run_ms, c->run_start, c->run_stop);
+        HIPCHK(hipMemcpy(cur_st, c->batch.cigar_cursor, sizeof cur_st, hipMemcpyDeviceToHost));
+        --c->runs_since_sync;
+    }
     c->h_used = cur_st[0];
     st = cur_st[4];
     if (c->stats_dev) {
@@ -541,6 +561,7 @@ int ipx_sync(ipx_ctx *c)
     if (st & IPX_STATUS_CIGAR_POOL) { set_err("device cigar pool exhausted (%u ops)", c->cigar_cap); return IPX_ERR_CIGAR_POOL; }
     if (st & IPX_STATUS_TB_SCRATCH) { set_err("traceback scratch exhausted"); return IPX_ERR_INTERNAL; }
     if (st & IPX_STATUS_INTERNAL) { set_err("internal: a kernel variant met a job it was not built for"); return IPX_ERR_INTERNAL; }
+    if (st & IPX_STATUS_RERUN) { set_err("internal: a job was left in a pass that did not run"); return IPX_ERR_INTERNAL; }
     return IPX_OK;
 }
 
@@ -670,6 +691,8 @@ float ipx_last_run_ms(ipx_ctx *c) { return c ? c->last_run_ms : 0.f; }
 
 // diagnostic: traceback routing of the last run -- out[0..6] jobs per first band width 1..7, out[7] jobs
 // handed to the general (one wave per job) kernel, out[8] unused
+int ipx_debug_reruns(ipx_ctx *c) { return c ? c->reruns : -1; }
+
 int ipx_debug_tb_counts(ipx_ctx *c, uint32_t *out)
 {
     if (!c || !out || !c->ws.tb_list_n) return IPX_ERR_ARG;

@@ -91,6 +91,8 @@ enum {
     IPX_ROUTE_TB_NO_DIAG = 16384,         // no anti-diagonal traceback tiers (k_tb_diag): bands wider than 7, doubled bands and small batches take one wave per job (k_tb_coop) as in r03
     IPX_ROUTE_NO_LAT = 32768,             // small batches too take the 8-lanes-per-read wavefront kernels (no latency tier: k_dp_skew W = 32)
     IPX_ROUTE_NO_LAT_PROOF = 131072,      // the latency tier keeps the lane-per-read overflow proof (k_prove_overflow) instead of k_prove_overflow_diag
+    IPX_ROUTE_NO_SPECULATE = 524288,      // the latency tier launches every pass, also those the previous run found empty
+    IPX_ROUTE_TEST_SKIP_ALL = 1048576 * 2, // (testing) every dynamic pass of the latency tier is predicted empty: the guard must notice and the run be repeated
     IPX_ROUTE_FORCE_LAT = 65536,          // (testing) the latency tier whatever the batch size, where its other conditions hold
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
@@ -168,4 +170,5 @@ enum {
     IPX_STATUS_REF_TOO_LONG = 4,
     IPX_STATUS_TB_SCRATCH = 8,
     IPX_STATUS_INTERNAL = 16,      // a kernel variant met a job it was not built for (host-side routing error)
+    IPX_STATUS_RERUN = 32,         // a job was left in a pass the host had predicted empty and not launched (latency tier, ipx_run_pipeline `skip`): the run is repeated with every pass
 };

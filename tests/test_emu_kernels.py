@@ -574,3 +574,33 @@ def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
     res = a.align(jobs2)
     mat = oracle_mod.dna_matrix(3, 2)
     assert a.status == 0 and all(res.as_dict(i) == port.align(reads[i], refs[rid[i]], mat, 3 if i < 19 else 1, 1) for i in range(20))
+
+
+def test_emu_latency_tier_speculation_is_caught_by_the_guard(emu, oracle_mod, port):
+    """r04: the latency tier leaves out passes the previous run found empty; k_tb_list notices a job left behind in one (status bit
+    IPX_STATUS_RERUN) and the run is repeated with every pass.  ROUTE_TEST_SKIP_ALL predicts EVERY dynamic pass empty: the first
+    attempt leaves every record without its reverse pass (and the 8-bit reads without their proofs), nothing of it may reach the
+    traceback kernels, and the repeated run must give the oracle's answers."""
+    rng = np.random.default_rng(515)
+    w = rng.integers(0, 4, 260).astype(np.int8)
+    reads = []
+    for i in range(24):
+        L = (150, 60, 100, 33)[i % 4]
+        st = int(rng.integers(0, 260 - L))
+        r = w[st:st + L].copy()
+        r[rng.integers(0, L, 2)] ^= 1
+        if i % 3 == 0:
+            r = np.concatenate([r[:L // 2], r[L // 2 + 2:]])
+        reads.append(r)
+    jobs = JobTable.from_sequences(reads, [w], [0] * len(reads), 3, 1, encoded=True)
+    mat = oracle_mod.dna_matrix(3, 2)
+    exp = [port.align(r, w, mat, 3, 1) for r in reads]
+    K_PACK = 12
+    for routing, rerun in ((R.ROUTE_FORCE_LAT | R.ROUTE_TEST_SKIP_ALL, True), (R.ROUTE_FORCE_LAT, False), (R.ROUTE_FORCE_LAT | R.ROUTE_TEST_SKIP_ALL | R.ROUTE_NO_SPECULATE, False)):
+        a = emu(0, 3, 2)
+        a.set_routing(routing)
+        res = a.align(jobs)
+        assert a.status == 0
+        assert bool(a.launches.get(a.key(K_PACK, 5))) == rerun, (routing, a.launches.get(a.key(K_PACK, 5)))
+        for i in range(len(reads)):
+            assert res.as_dict(i) == exp[i], (routing, i)
