@@ -56,10 +56,12 @@ def needs_build():
     return _stale(LIB_PATH, UNITS + HEADERS)
 
 
-def build(force=False, verbose=False, jobs=None):
+def build(force=False, verbose=False, jobs=None, variant=None):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU): one object per translation unit,
     in parallel, then one link.  Safe under torchrun, where every rank may find the library stale at once: the build is
     serialised by a file lock, objects and the library are written under temporary names and renamed into place."""
+    if variant is not None:
+        return _build_variant(variant, force, verbose, jobs)
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -79,12 +81,38 @@ def build(force=False, verbose=False, jobs=None):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(hipcc, force, verbose, jobs):
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# TEST variants of the library (same sources, one more define; built next to the tests, never loaded by the package):
+#   "noasm": -DIPX_NO_STRIPE_ASM -- the striped recurrence in its plain C++ form instead of the hand-scheduled inline asm (the form the
+#            CPU emulator runs): tests/test_gpu_parity.py holds the two against each other on the GPU
+VARIANTS = {"noasm": ["-DIPX_NO_STRIPE_ASM"]}
+
+
+def variant_path(variant):
+    return os.path.join(os.path.dirname(PKG_DIR), "tests", "variants", "libindelpost_hip_%s.so" % variant)
+
+
+def _build_variant(variant, force, verbose, jobs):
+    out = variant_path(variant)
+    if not force and not _stale(out, UNITS + HEADERS):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(out):
+            return out
+        raise IpxError("hipcc not found and %s is not built" % out)
+    bdir = os.path.join(CSRC, "build_" + variant)
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    return _build_locked(hipcc, True, verbose, jobs, bdir, out, VARIANTS[variant])
+
+
+def _build_locked(hipcc, force, verbose, jobs, build_dir=None, lib_path=None, extra=()):
+    BUILD_DIR_, LIB_PATH_ = build_dir or BUILD_DIR, lib_path or LIB_PATH
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + list(extra)
     tag = ".tmp%d" % os.getpid()
     objs, todo = [], []
     for src in UNITS:
-        obj = os.path.join(BUILD_DIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(BUILD_DIR_, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
             todo.append((obj, [hipcc] + flags + ["-c", src, "-o", obj + tag]))
@@ -104,12 +132,12 @@ def _build_locked(hipcc, force, verbose, jobs):
             os.replace(obj + tag, obj)
     if failed:
         raise failed
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH_ + tag] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
-    os.replace(LIB_PATH + tag, LIB_PATH)
-    return LIB_PATH
+    os.replace(LIB_PATH_ + tag, LIB_PATH_)
+    return LIB_PATH_
 
 
 _lib = None
@@ -123,7 +151,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise IpxError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    _lib = load(LIB_PATH)
+    return _lib
+
+
+def load(path):
+    """a shared object with the library's C ABI (the product library, or a test variant of it), signatures declared"""
+    L = C.CDLL(path)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
     L.ipx_device_count.restype = C.c_int
     L.ipx_create.restype = vp
@@ -177,7 +211,6 @@ def lib():
     "ipx_unpin_host", "ipx_align_batch",
               "ipx_set_profiling", "ipx_kernel_times"):
         getattr(L, f).restype = C.c_int
-    _lib = L
     return L
 
 

@@ -19,7 +19,7 @@ _OPS = "MIDNSHP=X"
 # identical results -- the tests run them all
 ROUTE_NO_WORD_FIRST, ROUTE_NO_PERM_PROFILE, ROUTE_NO_BRACKET, ROUTE_TB_NO_FUSE, ROUTE_NO_MC_LDS, ROUTE_NO_F16, ROUTE_NO_SKEW, ROUTE_NO_VL2 = 1, 2, 4, 8, 16, 32, 64, 128
 ROUTE_NO_PLAIN_FIRST, ROUTE_NO_CLASS_MERGE, ROUTE_NO_TIERS, ROUTE_NO_EXACT_DIRECT, ROUTE_TB_NO_WAVE_PER_JOB = 256, 512, 1024, 2048, 4096
-ROUTE_TB_NO_UNGAPPED, ROUTE_TB_NO_DIAG, ROUTE_NO_LAT, ROUTE_FORCE_LAT, ROUTE_NO_LAT_PROOF, ROUTE_NO_SPECULATE, ROUTE_TEST_SKIP_ALL = 8192, 16384, 32768, 65536, 131072, 524288, 2097152
+ROUTE_TB_NO_UNGAPPED, ROUTE_TB_NO_DIAG, ROUTE_NO_LAT, ROUTE_FORCE_LAT, ROUTE_NO_LAT_PROOF, ROUTE_NO_SPECULATE, ROUTE_TEST_SKIP_ALL, ROUTE_LAT64 = 8192, 16384, 32768, 65536, 131072, 524288, 2097152, 4194304
 
 # DNA_BASE_LUT of the reference (sswpy.pyx:16-25): A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, else 4.
 # Bytes >= 128 index the reference's table out of bounds (undefined); they map to N here.
@@ -315,8 +315,8 @@ def _p(a):
 class GpuAligner:
     """One GPU: HIP stream + HBM-resident batch + workspace (ipx_ctx)."""
 
-    def __init__(self, device=0, match_score=2, mismatch_penalty=2, matrix=None):
-        L = _lib.lib()
+    def __init__(self, device=0, match_score=2, mismatch_penalty=2, matrix=None, library=None):
+        L = library if library is not None else _lib.lib()         # (library: a test variant of the shared object, _lib.load)
         self._L = L
         self._ctx = L.ipx_create(int(device))
         if not self._ctx:
@@ -338,7 +338,7 @@ class GpuAligner:
 
     def _check(self, rc, what):
         if rc != 0:
-            raise IpxError("%s failed (%d): %s" % (what, rc, _lib.last_error()))
+            raise IpxError("%s failed (%d): %s" % (what, rc, self._L.ipx_last_error().decode(errors="replace")))
 
     def set_scoring(self, match_score=2, mismatch_penalty=2, matrix=None, flag=1, filters=0, filterd=0,
                     score_size=2):

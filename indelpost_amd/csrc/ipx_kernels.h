@@ -3571,10 +3571,12 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
     X(18, REV, BH) X(20, REV, BH) X(22, REV, BH) X(24, REV, BH) X(26, REV, BH) X(28, REV, BH) X(30, REV, BH) X(32, REV, BH)
 #define IPX_SKEW_BH_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_SKEW_BH_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
-// the latency tier (r04): 32 lanes per read, 1..8 segments = up to 256 rows; 16-bit passes (BH 0) and the plain recurrence in the 8-bit dialect (BH 2)
-#define IPX_LAT_FAMILY(X, REV, BH) X(1, REV, BH) X(2, REV, BH) X(3, REV, BH) X(4, REV, BH) X(5, REV, BH) X(6, REV, BH) X(7, REV, BH) X(8, REV, BH)
-#define IPX_LAT_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
-#define IPX_LAT_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH, IPX_LAT_W>(IpxBatch, IpxPlan, int, int, int);
+// the latency tier (r04): 32 lanes per read, 1..8 segments, or 64 lanes, 1..4 segments = up to 256 rows; 16-bit passes (BH 0) and the plain recurrence in
+// the 8-bit dialect (BH 2)
+#define IPX_LAT_FAMILY(X, REV, BH) X(1, REV, BH, 32) X(2, REV, BH, 32) X(3, REV, BH, 32) X(4, REV, BH, 32) X(5, REV, BH, 32) X(6, REV, BH, 32) X(7, REV, BH, 32) X(8, REV, BH, 32) \
+    X(1, REV, BH, 64) X(2, REV, BH, 64) X(3, REV, BH, 64) X(4, REV, BH, 64)
+#define IPX_LAT_DEFINE(S, REV, BH, W) template __global__ void k_dp_skew<S, REV, BH, W>(IpxBatch, IpxPlan, int, int, int);
+#define IPX_LAT_EXTERN(S, REV, BH, W) extern template __global__ void k_dp_skew<S, REV, BH, W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_DP_UNIT_X(X) IPX_LAT_FAMILY(X, false, 0) IPX_LAT_FAMILY(X, true, 0) IPX_LAT_FAMILY(X, false, 2) IPX_LAT_FAMILY(X, true, 2)
 #define IPX_DP_UNIT_K(X) IPX_SKEW_FAMILY(X, false)
 #define IPX_DP_UNIT_L(X) IPX_SKEW_FAMILY(X, true)

@@ -61,14 +61,17 @@ struct IpxDims {
     uint8_t high_sets;                 // (bracket flow) the upper-bound stage runs as a wavefront, launched from `set`
     int word_from;                     // 16-bit fast-gap classes below this one are planned into `set`; from it on: class-by-class launches / k_dp_long
     int plain_max_len;                 // plain-first flow: reads up to this length take the plain kernels
-    uint8_t lat;                       // latency tier (r04): a small batch whose wavefront passes run at IPX_LAT_W lanes per read, 2 * 64 / IPX_LAT_W reads per
+    uint8_t lat;                       // latency tier (r04): 0, or the lanes per read (32 / 64) a small batch's wavefront passes run at -- 2 * 64 / lat reads per
                                        //   tile, every class of a pass in ONE launch (ipx_plan_classes)
 };
 #ifndef IPX_LAT_MAX_JOBS
 #define IPX_LAT_MAX_JOBS 4096          // batches up to this size take the latency tier: 1 024 SIMDs x one four-read tile
 #endif
+#ifndef IPX_LAT64_MAX_JOBS
+#define IPX_LAT64_MAX_JOBS (IPX_LAT_MAX_JOBS * 3 / 8)   // ... up to this size (1 536) at 64 lanes per read: two-read tiles, 768 of 1 024 SIMDs
+#endif
 // alignments per tile of the passes the wavefront kernels serve
-static inline int ipx_skew_na(const IpxDims &d) { return d.lat ? 2 * (64 / IPX_LAT_W) : 16; }
+static inline int ipx_skew_na(const IpxDims &d) { return d.lat ? 2 * (64 / d.lat) : 16; }
 
 static inline void ipx_dims_add_read(IpxDims &d, int len, bool slow)
 {
@@ -282,22 +285,24 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
 // the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).  The classes of `set` that fall into one occupancy
 // (r03's shared tier launches, k_dp_skew_tier, are gone: see ipx_kernels.h.)
 template <class BE, bool REV, int BH>
-static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing, bool lat = false)
+static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing, int lat = 0)
 {
     if (lat && BH != 1) {
-        // latency tier: IPX_LAT_W lanes per read, the kernel with ceil(rows / IPX_LAT_W) segments serves the class (ipx_plan_classes listed every
+        // latency tier: LW = 32 or 64 lanes per read, the kernel with ceil(rows / LW) segments serves the class (ipx_plan_classes listed every
         // class of the pass under one)
-        const int lds = ipx_dp_lds_bytes(IPX_LAT_W, 0, REV, maxcols, true, routing);
-        const int pflag = pass | (ipx_dp_mc_in_lds(IPX_LAT_W, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
+        const int LW = lat;
+        const int lds = ipx_dp_lds_bytes(LW, 0, REV, maxcols, true, routing);
+        const int pflag = pass | (ipx_dp_mc_in_lds(LW, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
         for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
             if (!set[c]) continue;
             const int rows = BH ? 16 * c : 8 * c;
-            int S = (rows + IPX_LAT_W - 1) / IPX_LAT_W;
+            int S = (rows + LW - 1) / LW;
             if (S < 1) S = 1;
-            be.note_dp(IPX_KEY(kclass, c), pass, c, 2 * (64 / IPX_LAT_W));
+            be.note_dp(IPX_KEY(kclass, c), pass, c, 2 * (64 / LW));
             be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
-#define IPX_LAT_CASE(N) case N: if constexpr (BH != 1) be.launch(IPX_KEY(kclass, c), k_dp_skew<N, REV, BH, IPX_LAT_W>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); break;
-            switch (S) { IPX_LAT_CASE(1) IPX_LAT_CASE(2) IPX_LAT_CASE(3) IPX_LAT_CASE(4) IPX_LAT_CASE(5) IPX_LAT_CASE(6) IPX_LAT_CASE(7) IPX_LAT_CASE(8) default: break; }
+#define IPX_LAT_CASE(N, LWC) case N: if constexpr (BH != 1) be.launch(IPX_KEY(kclass, c), k_dp_skew<N, REV, BH, LWC>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); break;
+            if (LW == 64) switch (S) { IPX_LAT_CASE(1, 64) IPX_LAT_CASE(2, 64) IPX_LAT_CASE(3, 64) IPX_LAT_CASE(4, 64) default: break; }
+            else switch (S) { IPX_LAT_CASE(1, 32) IPX_LAT_CASE(2, 32) IPX_LAT_CASE(3, 32) IPX_LAT_CASE(4, 32) IPX_LAT_CASE(5, 32) IPX_LAT_CASE(6, 32) IPX_LAT_CASE(7, 32) IPX_LAT_CASE(8, 32) default: break; }
 #undef IPX_LAT_CASE
         }
         return;
@@ -405,7 +410,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     const int prove_grid2 = prove_nchunk >= 512 ? (prove_grid1 + 1) / 2 : prove_grid1;
     if (wf) {
         // long reads: 16-bit pass first, then try to prove the 8-bit overflow from the end diagonal
-        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, d.lat != 0);
+        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST], maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, d.lat);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FIRST], ws, d.has16_wf, maxcols, IPX_K_WORD_FIRST, IPX_PASS_WORD_FIRST, routing, 3, word_from, 16);
         int cap = 64 * d.max_read_len;                            // one wave's reads
         if (cap > 60 * 1024) cap = 60 * 1024;
@@ -421,7 +426,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             // lower-bound stage (compared with the plain outputs) and, failing that, the stepped pass.  (Jobs with gap_open <= gap_ext
             // start in the stepped pass: next_pass_key.)
             if (d.any_low) {
-                ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing, d.lat != 0);
+                ipx_launch_skew_set<BE, false, 2>(be, b, ws.plan[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST], maxcols, IPX_K_BYTE_PLAIN, IPX_PASS_BYTE_FIRST, routing, d.lat);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 0), k_prove_plain<false>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
                 if (!b.exact_direct && !skip(IPX_PASS_BYTE_LOW2)) {
                     ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_LOW2], IPX_PASS_BYTE_LOW2, low2 ? 16 : 8);
@@ -458,7 +463,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
     }
     if (b.score_size != 0 && !(b.score_size == 2 && skip(IPX_PASS_WORD_FWD))) {   // 16-bit forward pass (ssw.c:844-847, 853-855)
         ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_FWD], IPX_PASS_WORD_FWD, ipx_skew_na(d), b.score_size == 1);
-        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, d.lat != 0);
+        if (d.word_sets) ipx_launch_skew_set<BE, false, 0>(be, b, ws.plan[IPX_PASS_WORD_FWD], d.set[IPX_PASS_WORD_FWD], maxcols, IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, d.lat);
         ipx_launch_dp<BE, 8, false, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_FWD], ws, b.score_size == 1 ? has16_all : d.has16_low, maxcols,
                                                      IPX_K_WORD_FWD, IPX_PASS_WORD_FWD, routing, 3, word_from, 16);
     }
@@ -467,7 +472,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             if (d.plain_first && !skip(IPX_PASS_BYTE_REV_PLAIN)) {
                 // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, ipx_skew_na(d));
-                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing, d.lat != 0);
+                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing, d.lat);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
             }
             if (!skip(IPX_PASS_BYTE_REV)) {
@@ -477,7 +482,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         }
         if (b.score_size != 0 && !skip(IPX_PASS_WORD_REV)) {
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, ipx_skew_na(d));
-            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, d.lat != 0);
+            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, d.lat);
             ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], ws, has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, 3, word_from, 16);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
@@ -678,7 +683,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
     // a pass has ONE tile size) and every 16-bit class within the wavefront kernels' reach.  Every class of a pass is then listed under the
     // pass's longest one: ONE launch per pass -- on a chip with more SIMDs than the batch has tiles a launch lasts as long as its longest
     // tile whatever its size, and two launches last twice that.
-    bool lat = merge && !(routing & IPX_ROUTE_NO_LAT) && (b.n_jobs <= IPX_LAT_MAX_JOBS || (routing & IPX_ROUTE_FORCE_LAT)) && all16 <= fmax16 && (all8 < 0 || 16 * all8 <= 8 * IPX_LAT_W);
+    bool lat = merge && !(routing & IPX_ROUTE_NO_LAT) && (b.n_jobs <= IPX_LAT_MAX_JOBS || (routing & IPX_ROUTE_FORCE_LAT)) && all16 <= fmax16 && (all8 < 0 || all8 <= 16);
     for (int len = 0; lat && len <= IPX_MAX_READ_LEN; ++len) if (d.lenhist[1][len]) lat = false;
     auto single_class = [](const uint32_t *n1, const uint32_t *n2, int top, uint8_t *map, uint8_t *set) {
         int t = -1;
@@ -689,7 +694,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
         for (int c = 0; c <= t; ++c) map[c] = (uint8_t)t;
     };
     if (lat && b.score_size != 0 && top16 >= 1) {
-        d.lat = 1;
+        d.lat = (b.n_jobs <= IPX_LAT64_MAX_JOBS || (routing & IPX_ROUTE_LAT64)) ? 64 : 32;
         d.word_sets = 1;
         d.word_from = fmax16 + 1;
         single_class(n16wf, nullptr, top16, d.cls_map[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST]);
