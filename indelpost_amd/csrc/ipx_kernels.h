@@ -1416,8 +1416,12 @@ IPX_HD constexpr int ipx_skew_waves(int smax, bool rev) { return (smax >= 20 && 
 template <int W> IPX_DEV uint32_t skew_shr1(uint32_t v) { return W <= 16 ? xl_row_shr1(v) : xl_wave_shr1(v); }
 template <int SMAX, bool REV, int BH, int W = 8>
 IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t first, const int cnt, const int pass, uint32_t *maxcol, const bool mc_lds,
-                          unsigned char *lds, const uint32_t nz)
+                          unsigned char *lds, const uint32_t nz, uint32_t *winlds = nullptr, const int winstride = 0)
 {
+    // LATENCY TIER (W >= 32): the tile's windows are staged in LDS (winlds: winstride words per read).  The throughput form fetches one dword of
+    // window letters per group of four steps from global memory, one group ahead: four steps of ~200 instructions hide that, four steps of
+    // 50-70 do not -- the first W = 64 kernel spent 330 ns per step waiting for it (121 us per pass where W = 32 took 71).
+    constexpr bool WINLDS = W >= 32;
     static_assert(!(BH == 1 && REV), "the upper-bound stage of the bracket is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
     static_assert(W == 8 || W == 32 || W == 64, "8 lanes per read (16 reads per wave), or the latency tier's 32 / 64");
@@ -1529,8 +1533,26 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
         int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
         if (k1 < 0) k1 = 0;
         if (k1 > kmax[h]) k1 = kmax[h];
-        cur[h] = load_global_u32(refw[h] + (k0 > kmax[h] ? kmax[h] : k0));
-        nxt[h] = load_global_u32(refw[h] + k1);
+        if (WINLDS) {
+            uint32_t *wl = winlds + (size_t)(2 * g + h) * (size_t)winstride;
+            for (int q = l; q <= kmax[h] && q < winstride; q += W) wl[q] = load_global_u32(refw[h] + q);
+        } else {
+            cur[h] = load_global_u32(refw[h] + (k0 > kmax[h] ? kmax[h] : k0));
+            nxt[h] = load_global_u32(refw[h] + k1);
+        }
+    }
+    if (WINLDS) {
+        IPX_SYNC();                                                 // the staged windows are visible to every lane of their group
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t *wl = winlds + (size_t)(2 * g + h) * (size_t)winstride;
+            const int k0 = REV ? (idx0[h] >> 2) : 0;
+            int k1 = REV ? (idx0[h] >> 2) - 1 : 1;
+            if (k1 < 0) k1 = 0;
+            if (k1 > kmax[h]) k1 = kmax[h];
+            cur[h] = wl[k0 > kmax[h] ? kmax[h] : k0];
+            nxt[h] = wl[k1];
+        }
     }
 
     int tend = -1;                                              // (reverse) step at which every read has passed its last column
@@ -1627,14 +1649,16 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
         // register at once and every group waited for its own request.)
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
-        IPX_VMEM_FENCE();
+        if (!WINLDS) IPX_VMEM_FENCE();
         IPX_UNROLL
         for (int h = 0; h < 2; ++h) {
             // (unsigned, one minimum: the word index costs the vector ALU a v_min and the 64-bit address add, nothing else)
             int kr = (idx0[h] >> 2) - ((t0 >> 2) + 2);
             if (kr < 0) kr = 0;
             const uint32_t k = REV ? (uint32_t)kr : (uint32_t)((t0 >> 2) + 2);
-            nxt[h] = load_global_u32(refw[h] + (k < (uint32_t)kmax[h] ? k : (uint32_t)kmax[h]));
+            const uint32_t kk = k < (uint32_t)kmax[h] ? k : (uint32_t)kmax[h];
+            if (WINLDS) nxt[h] = (winlds + (size_t)(2 * g + h) * (size_t)winstride)[kk < (uint32_t)winstride ? kk : (uint32_t)winstride - 1u];
+            else nxt[h] = load_global_u32(refw[h] + kk);
         }
     }
 
@@ -1789,6 +1813,13 @@ IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBa
         if (p.tile_off[cls] + want >= p.tile_off[cls + 1]) break;
         const uint32_t first = p.cls_off[cls] + want * NA;
         const uint32_t avail = p.cls_off[cls + 1] - first;
+        if (W >= 32) {
+            // (latency tier) window letters of the tile's reads staged behind the score table and the column maxima: winstride words per read
+            const int winstride = (maxcols + 3) / 4 + 4;
+            uint32_t *winlds = (uint32_t *)(lds + 128 + (mc_lds ? G * maxcols * 4 : 0));
+            IPX_SYNC();                                             // (the previous tile's finalisation has read its column maxima and windows)
+            dp_skew_tile<SMAX, REV, BH, W>(b, p, first, avail < (uint32_t)NA ? (int)avail : NA, pass, maxcol, mc_lds, lds, nz, winlds, winstride);
+        } else
         dp_skew_tile<SMAX, REV, BH, W>(b, p, first, avail < (uint32_t)NA ? (int)avail : NA, pass, maxcol, mc_lds, lds, nz);
     }
 }

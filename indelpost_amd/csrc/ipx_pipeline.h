@@ -291,7 +291,8 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
         // latency tier: LW = 32 or 64 lanes per read, the kernel with ceil(rows / LW) segments serves the class (ipx_plan_classes listed every
         // class of the pass under one)
         const int LW = lat;
-        const int lds = ipx_dp_lds_bytes(LW, 0, REV, maxcols, true, routing);
+        // (+ the tile's windows staged in LDS: (maxcols + 3) / 4 + 4 words per read, 2 * 64 / LW reads: k_dp_skew W >= 32)
+        const int lds = ipx_dp_lds_bytes(LW, 0, REV, maxcols, true, routing) + 2 * (64 / LW) * ((maxcols + 3) / 4 + 4) * 4;
         const int pflag = pass | (ipx_dp_mc_in_lds(LW, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
         for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
             if (!set[c]) continue;
