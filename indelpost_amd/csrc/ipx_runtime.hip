@@ -108,7 +108,10 @@ struct HipBackend {
     hipError_t err = hipSuccess;
     int dp_grid() const
     {
-        const int64_t g = c->n_jobs / 8 + IPX_NUM_CLASSES + 1;
+        // (every tile of the largest pass a block of its own, twice over for 16-job tiles; the latency tier's tiles hold 2 or 4 jobs --
+        //  r04: with n / 8 its 500 tiles of a 1 000-job call got 256 blocks and every block walked two tiles, 124 us instead of 62)
+        const int64_t per = c->dims.lat ? 2 * (64 / c->dims.lat) : 8;
+        const int64_t g = c->n_jobs / per + IPX_NUM_CLASSES + 1;
         return (int)(g < c->dp_grid_cap ? g : c->dp_grid_cap);
     }
     // Which passes a job takes is decided on the device, so the host does not know how many tiles a DP launch will
