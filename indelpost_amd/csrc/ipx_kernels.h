@@ -1424,7 +1424,7 @@ IPX_DEV void dp_skew_tile(const IpxBatch &b, const IpxPlan &p, const uint32_t fi
     constexpr bool WINLDS = W >= 32;
     static_assert(!(BH == 1 && REV), "the upper-bound stage of the bracket is a forward pass");
     constexpr int SA = SMAX > 0 ? SMAX : 1;
-    static_assert(W == 8 || W == 32 || W == 64, "8 lanes per read (16 reads per wave), or the latency tier's 32 / 64");
+    static_assert(W == 8 || W == 32, "8 lanes per read (16 reads per wave), or the latency tier's 32");
     constexpr int G = 64 / W, S = SMAX;
     const int lane = lane_id();
     const int g = lane / W, l = lane % W;
@@ -2716,8 +2716,8 @@ IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint3
                     if (b.tb_diag) {
                         b.tb_bw[i] = 0;                                                        // (every tier starts the job from its own first band)
                         // (a small batch starts in a WIDER tier than its band needs: more lanes per job = more widths of the doubling sequence
-                        //  side by side -- all_general 1: at least 32 lanes per job, 2: 64)
-                        const int lo = all_general >= 2 ? 63 : all_general == 1 ? 31 : 15;
+                        //  side by side -- all_general 1: at least 32 lanes per job, 2: 64, 3: 16)
+                        const int lo = all_general == 2 ? 63 : all_general == 1 ? 31 : 15;      // (3: 16 lanes at least)
                         const int bt = bw > lo ? bw : lo;
                         const int tier = (readLen > IPX_TBD_ROWS || readLen < 1 || refLen < 1) ? IPX_TB_CLS_COOP
                                          : bt <= 15 ? IPX_TB_CLS_DIAG : bt <= 31 ? IPX_TB_CLS_DIAG + 1 : bt <= 63 ? IPX_TB_CLS_DIAG + 2 : IPX_TB_CLS_COOP;
@@ -3602,10 +3602,10 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
     X(18, REV, BH) X(20, REV, BH) X(22, REV, BH) X(24, REV, BH) X(26, REV, BH) X(28, REV, BH) X(30, REV, BH) X(32, REV, BH)
 #define IPX_SKEW_BH_DEFINE(S, REV, BH) template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_SKEW_BH_EXTERN(S, REV, BH) extern template __global__ void k_dp_skew<S, REV, BH>(IpxBatch, IpxPlan, int, int, int);
-// the latency tier (r04): 32 lanes per read, 1..8 segments, or 64 lanes, 1..4 segments = up to 256 rows; 16-bit passes (BH 0) and the plain recurrence in
-// the 8-bit dialect (BH 2)
-#define IPX_LAT_FAMILY(X, REV, BH) X(1, REV, BH, 32) X(2, REV, BH, 32) X(3, REV, BH, 32) X(4, REV, BH, 32) X(5, REV, BH, 32) X(6, REV, BH, 32) X(7, REV, BH, 32) X(8, REV, BH, 32) \
-    X(1, REV, BH, 64) X(2, REV, BH, 64) X(3, REV, BH, 64) X(4, REV, BH, 64)
+// the latency tier (r04): 32 lanes per read, 1..8 segments = up to 256 rows; 16-bit passes (BH 0) and the plain recurrence in the 8-bit dialect (BH 2).
+// (64 lanes per read -- two reads per wave, 1..4 segments -- was built and measured too: 50 instead of 70 instructions per step and the SAME
+//  time per pass, 66 against 71 us: one wave per SIMD is bound by the dependent chain of a step, ~180 ns whatever its length.  Not kept.)
+#define IPX_LAT_FAMILY(X, REV, BH) X(1, REV, BH, 32) X(2, REV, BH, 32) X(3, REV, BH, 32) X(4, REV, BH, 32) X(5, REV, BH, 32) X(6, REV, BH, 32) X(7, REV, BH, 32) X(8, REV, BH, 32)
 #define IPX_LAT_DEFINE(S, REV, BH, W) template __global__ void k_dp_skew<S, REV, BH, W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_LAT_EXTERN(S, REV, BH, W) extern template __global__ void k_dp_skew<S, REV, BH, W>(IpxBatch, IpxPlan, int, int, int);
 #define IPX_DP_UNIT_X(X) IPX_LAT_FAMILY(X, false, 0) IPX_LAT_FAMILY(X, true, 0) IPX_LAT_FAMILY(X, false, 2) IPX_LAT_FAMILY(X, true, 2)

@@ -61,14 +61,11 @@ struct IpxDims {
     uint8_t high_sets;                 // (bracket flow) the upper-bound stage runs as a wavefront, launched from `set`
     int word_from;                     // 16-bit fast-gap classes below this one are planned into `set`; from it on: class-by-class launches / k_dp_long
     int plain_max_len;                 // plain-first flow: reads up to this length take the plain kernels
-    uint8_t lat;                       // latency tier (r04): 0, or the lanes per read (32 / 64) a small batch's wavefront passes run at -- 2 * 64 / lat reads per
+    uint8_t lat;                       // latency tier (r04): 0, or the lanes per read (32) a small batch's wavefront passes run at -- 2 * 64 / lat reads per
                                        //   tile, every class of a pass in ONE launch (ipx_plan_classes)
 };
 #ifndef IPX_LAT_MAX_JOBS
 #define IPX_LAT_MAX_JOBS 4096          // batches up to this size take the latency tier: 1 024 SIMDs x one four-read tile
-#endif
-#ifndef IPX_LAT64_MAX_JOBS
-#define IPX_LAT64_MAX_JOBS (IPX_LAT_MAX_JOBS * 3 / 8)   // ... up to this size (1 536) at 64 lanes per read: two-read tiles, 768 of 1 024 SIMDs
 #endif
 // alignments per tile of the passes the wavefront kernels serve
 static inline int ipx_skew_na(const IpxDims &d) { return d.lat ? 2 * (64 / d.lat) : 16; }
@@ -302,8 +299,7 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
             be.note_dp(IPX_KEY(kclass, c), pass, c, 2 * (64 / LW));
             be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
 #define IPX_LAT_CASE(N, LWC) case N: if constexpr (BH != 1) be.launch(IPX_KEY(kclass, c), k_dp_skew<N, REV, BH, LWC>, be.dp_grid(pass, c), 64, lds, b, p, c, maxcols, pflag); break;
-            if (LW == 64) switch (S) { IPX_LAT_CASE(1, 64) IPX_LAT_CASE(2, 64) IPX_LAT_CASE(3, 64) IPX_LAT_CASE(4, 64) default: break; }
-            else switch (S) { IPX_LAT_CASE(1, 32) IPX_LAT_CASE(2, 32) IPX_LAT_CASE(3, 32) IPX_LAT_CASE(4, 32) IPX_LAT_CASE(5, 32) IPX_LAT_CASE(6, 32) IPX_LAT_CASE(7, 32) IPX_LAT_CASE(8, 32) default: break; }
+            switch (S) { IPX_LAT_CASE(1, 32) IPX_LAT_CASE(2, 32) IPX_LAT_CASE(3, 32) IPX_LAT_CASE(4, 32) IPX_LAT_CASE(5, 32) IPX_LAT_CASE(6, 32) IPX_LAT_CASE(7, 32) IPX_LAT_CASE(8, 32) default: break; }
 #undef IPX_LAT_CASE
         }
         return;
@@ -489,9 +485,10 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)
             // a SMALL batch has more SIMDs than jobs: one wave per job (k_tb_coop: a DP row spread over the lanes) then finishes a typical job in
             // a fifth of the time one lane needs for it (r03, 1000 jobs: 0.76 -> 0.42 ms of traceback), and the lane-per-job launch is skipped
-            // (with the anti-diagonal tiers: 1 = small batch, every job at 32 lanes at least; 2 = tiny batch, one job per wave)
+            // (with the anti-diagonal tiers: 2 = tiny batch, one job per wave; 1 = small batch, every job at 32 lanes at least; 3 = at 16 lanes at
+            //  least -- six one-wave blocks of these kernels are resident per CU, 1 536 in all: more waves than that take a second round)
             const int tb_all_general = (routing & IPX_ROUTE_TB_NO_WAVE_PER_JOB) ? 0 : !b.tb_diag ? (b.n_jobs <= 2048 ? 1 : 0)
-                                       : b.n_jobs <= IPX_TB_TINY_DIAG ? 2 : b.n_jobs <= IPX_TB_SMALL_DIAG ? 1 : 0;
+                                       : b.n_jobs <= IPX_TB_TINY_DIAG ? 2 : b.n_jobs <= 3 * IPX_TB_TINY_DIAG ? 1 : b.n_jobs <= IPX_TB_SMALL_DIAG ? 3 : 0;
             be.launch(IPX_KEY(IPX_K_TB_LIST, 0), k_tb_list, be.plan_grid(b.n_jobs), IPX_PLAN_BLOCK, 64, b, ws.tb_list, ws.tb_list_n, ws.tb_esc, tb_all_general,
                       ((routing & IPX_ROUTE_TB_NO_UNGAPPED) || tb_all_general) ? 0 : 1);   // (a small batch has a wave for every job: the check would only add its own latency)
             // rows of direction words that fit in LDS next to the CIGAR buffer (longer jobs take the general kernel)
@@ -695,7 +692,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
         for (int c = 0; c <= t; ++c) map[c] = (uint8_t)t;
     };
     if (lat && b.score_size != 0 && top16 >= 1) {
-        d.lat = (b.n_jobs <= IPX_LAT64_MAX_JOBS || (routing & IPX_ROUTE_LAT64)) ? 64 : 32;
+        d.lat = 32;
         d.word_sets = 1;
         d.word_from = fmax16 + 1;
         single_class(n16wf, nullptr, top16, d.cls_map[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FIRST]);

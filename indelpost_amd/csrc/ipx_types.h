@@ -93,13 +93,11 @@ enum {
     IPX_ROUTE_NO_LAT_PROOF = 131072,      // the latency tier keeps the lane-per-read overflow proof (k_prove_overflow) instead of k_prove_overflow_diag
     IPX_ROUTE_NO_SPECULATE = 524288,      // the latency tier launches every pass, also those the previous run found empty
     IPX_ROUTE_TEST_SKIP_ALL = 1048576 * 2, // (testing) every dynamic pass of the latency tier is predicted empty: the guard must notice and the run be repeated
-    IPX_ROUTE_LAT64 = 4194304,            // (with FORCE_LAT, testing) the forced tier at 64 lanes per read
     IPX_ROUTE_FORCE_LAT = 65536,          // (testing) the latency tier whatever the batch size, where its other conditions hold
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
 
-// lanes per read of the latency tier (k_dp_skew W; IpxDims::lat): 32 (four reads per wave, up to 8 segments) for small batches, 64 (two reads per wave,
-// up to 4 segments) for tiny ones -- both reach 256 rows
+// lanes per read of the latency tier (k_dp_skew W; IpxDims::lat): 32 -- four reads per wave, up to 8 segments = 256 rows
 #define IPX_MAX_SEG 64       // largest segLen handled by the register-resident kernels
 #define IPX_SLOW_BASE (IPX_MAX_SEG + 1)      // class of a job with gap_open <= gap_ext: segLen + IPX_SLOW_BASE
 #define IPX_NUM_CLASSES (2 * IPX_SLOW_BASE)

@@ -521,8 +521,8 @@ def test_emu_anti_diagonal_traceback_tiers(emu, oracle_mod, port):
     assert a.tb_jobs[1] == 0 and a.tb_jobs[2] == 0 and a.tb_jobs[3] >= 40, a.tb_jobs
 
 def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
-    """r04, k_dp_skew<S, REV, BH, 32 / 64>: the wavefront passes of a small batch at 32 lanes per read (four reads per wave; ROUTE_LAT64: 64 lanes,
-    two reads per wave, what batches of up to 1 536 jobs take), every class of a pass in one launch, a whole-wavefront lane shift.  Reads of 1..256 bp against windows shorter and longer than the reads, with N, with
+    """r04, k_dp_skew<S, REV, BH, 32>: the wavefront passes of a small batch at 32 lanes per read (four reads per wave, every class of a pass
+    in one launch, a whole-wavefront lane shift, windows staged in LDS).  Reads of 1..256 bp against windows shorter and longer than the reads, with N, with
     indels, empty reads; gap penalties with gap_open > gap_ext only (anything else keeps the batch off the tier); scorings that put reads
     in the 16-bit passes (3,2), in the plain 8-bit flow (1,1) and in both (2,2); every field and CIGAR against the oracle, and the same
     batch with the tier forced off.  (ROUTE_FORCE_LAT: the emulator build never takes the tier by itself.)"""
@@ -557,8 +557,7 @@ def test_emu_latency_tier_32_lanes_per_read(emu, oracle_mod, port):
         mat = oracle_mod.dna_matrix(*scoring)
         exp = [port.align(r, refs[rid[i]], mat, go[i], ge[i]) for i, r in enumerate(reads)]
         got = {}
-        for routing in ((R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_LAT64, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT_PROOF, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST) if scoring == (3, 2)
-                        else (R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_LAT64)):
+        for routing in ((R.ROUTE_FORCE_LAT, R.ROUTE_FORCE_LAT | R.ROUTE_NO_LAT_PROOF, R.ROUTE_FORCE_LAT | R.ROUTE_NO_PLAIN_FIRST) if scoring == (3, 2) else (R.ROUTE_FORCE_LAT,)):
             a = emu(0, *scoring)
             a.set_routing(routing)
             res = a.align(jobs)
