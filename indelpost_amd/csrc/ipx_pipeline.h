@@ -65,7 +65,7 @@ struct IpxDims {
                                        //   tile, every class of a pass in ONE launch (ipx_plan_classes)
 };
 #ifndef IPX_LAT_MAX_JOBS
-#define IPX_LAT_MAX_JOBS 4096          // batches up to this size take the latency tier: 1 024 SIMDs x one four-read tile
+#define IPX_LAT_MAX_JOBS 8192          // batches up to this size take the latency tier: 2 048 four-read tiles, two per SIMD (r04: 8 000 jobs 0.67 ms with the throughput kernels)
 #endif
 // alignments per tile of the passes the wavefront kernels serve
 static inline int ipx_skew_na(const IpxDims &d) { return d.lat ? 2 * (64 / d.lat) : 16; }

@@ -97,6 +97,7 @@ struct ipx_ctx {
     uint32_t *stats_dev = nullptr;              // ... and where the planner leaves them
     uint8_t *cls_map_dev = nullptr;             // IpxBatch::cls_map (filled from IpxDims::cls_map when the static plans are built)
     bool prev_valid = false;
+    std::vector<uint32_t> sync_back;            // ipx_sync's read-back buffer
     bool speculated = false;                    // the last ipx_run left out passes predicted empty: a job found in one makes ipx_sync repeat the run
     int reruns = 0;                             // ... how often that has happened (ipx_debug_reruns)
     std::map<const void *, int> lds_attr;       // kernels whose dynamic-LDS limit was raised
@@ -426,6 +427,8 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     uint32_t *sm = c->small.as<uint32_t>();
     c->ws.plan_tables = sm; sm += IPX_PLAN_TABLE_WORDS;
     uint32_t *offs = sm; sm += (size_t)IPX_NUM_PASSES * 2 * (IPX_NUM_CLASSES + 1);
+    uint32_t *cursor = sm; sm += 4;                           // cursor (4 words), status (4 words) and the planner statistics are neighbours:
+    uint32_t *status = sm; sm += 4;                           //   ipx_sync reads all three back with ONE copy
     c->stats_dev = sm; sm += (size_t)IPX_NUM_PASSES * (IPX_NUM_CLASSES + 1);
     c->ws.exact_starters = sm; sm += IPX_NUM_CLASSES;
     for (int ps = 0; ps < IPX_NUM_PASSES; ++ps) {
@@ -441,8 +444,6 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     c->ws.tb_esc = c->tb_esc.as<uint32_t>();
     c->ws.tb_list_n = sm; sm += IPX_TB_NCOUNTERS;
     c->ws.tb_esc_n = c->ws.tb_list_n + IPX_TB_CLS_COOP;
-    uint32_t *cursor = sm; sm += 4;
-    uint32_t *status = sm; sm += 4;
     c->cls_map_dev = (uint8_t *)sm; sm += (IPX_NUM_PASSES * IPX_NUM_CLASSES + 3) / 4;
     HIPCHK(hipMemsetAsync(c->small.p, 0, 4 * (size_t)(sm - c->small.as<uint32_t>()), s));
 
@@ -531,23 +532,26 @@ int ipx_sync(ipx_ctx *c)
         c->ev_next = 0;
     }
     if (c->n_jobs == 0) { c->runs_since_sync = 0; return IPX_OK; }
-    uint32_t st = 0, cur_st[8] = {0};
-    // cursor (4 words) and status (4 words) are neighbours in the small-table buffer: one read-back for both
-    HIPCHK(hipMemcpy(cur_st, c->batch.cigar_cursor, sizeof cur_st, hipMemcpyDeviceToHost));
-    if ((cur_st[4] & IPX_STATUS_RERUN) && c->speculated) {
+    uint32_t st = 0;
+    // cursor, status and the planner's tile counts in one read-back (neighbours in the small-table buffer)
+    std::vector<uint32_t> &back = c->sync_back;
+    back.resize(8 + sizeof c->prev_tiles / 4);
+    const size_t back_bytes = c->stats_dev ? 4 * back.size() : 32;
+    HIPCHK(hipMemcpy(back.data(), c->batch.cigar_cursor, back_bytes, hipMemcpyDeviceToHost));
+    if ((back[4] & IPX_STATUS_RERUN) && c->speculated) {
         // a job sat in a pass that was predicted empty and left out (ipx_run_pipeline, speculation): the whole run again, every pass launched
         ++c->reruns;
         const int rc = ipx_run_impl(c, false);
         if (rc != IPX_OK) return rc;
         HIPCHK(hipStreamSynchronize(c->stream));
         (void)hipEventElapsedTime(&c->last_run_ms, c->run_start, c->run_stop);
-        HIPCHK(hipMemcpy(cur_st, c->batch.cigar_cursor, sizeof cur_st, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(back.data(), c->batch.cigar_cursor, back_bytes, hipMemcpyDeviceToHost));
         --c->runs_since_sync;
     }
-    c->h_used = cur_st[0];
-    st = cur_st[4];
+    c->h_used = back[0];
+    st = back[4];
     if (c->stats_dev) {
-        HIPCHK(hipMemcpy(c->prev_tiles, c->stats_dev, sizeof c->prev_tiles, hipMemcpyDeviceToHost));
+        memcpy(c->prev_tiles, back.data() + 8, sizeof c->prev_tiles);
         c->prev_valid = true;
         if (c->profiling)
             for (int k = 0; k < IPX_NUM_KEYS; ++k)
@@ -575,7 +579,8 @@ int ipx_download(ipx_ctx *c, ipx_result *out, uint32_t *cigar_pool, int64_t ciga
     uint32_t used = 0;
     if (c->n_jobs > 0) {
         HIPCHK(hipMemcpy(out, c->res.p, 32 * (size_t)c->n_jobs, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&used, c->batch.cigar_cursor, 4, hipMemcpyDeviceToHost));
+        if (c->runs_since_sync == 0) used = c->h_used;        // (read back by ipx_sync)
+        else HIPCHK(hipMemcpy(&used, c->batch.cigar_cursor, 4, hipMemcpyDeviceToHost));
     }
     if (n_cigar_ops) *n_cigar_ops = used;
     if (used) {
