@@ -38,7 +38,7 @@ struct IpxWorkspace {
 #define IPX_TBF_ROWCAP 512  // rows of direction words per fast-traceback block
 #ifndef IPX_TB_SMALL_DIAG
 #define IPX_TB_TINY_DIAG 1024    // ... up to this many: one job per wave (64 lanes: five widths of the doubling sequence side by side)
-#define IPX_TB_SMALL_DIAG 8192   // batches up to this many jobs: every traceback takes an anti-diagonal tier (4 jobs per wave at most) instead of a lane
+#define IPX_TB_SMALL_DIAG 16384  // batches up to this many jobs: every traceback takes an anti-diagonal tier (4 jobs per wave at most) instead of a lane
 #endif
 #define IPX_MAX_EXACT 32     // segLen classes 0..32 have their own straight-line instantiation
 #define IPX_MAX_READ_LEN IPX_LONG_MAX_READ   // longest read the library takes (beyond 8 * IPX_MAX_SEG = 512 bp: k_dp_long)
@@ -65,7 +65,7 @@ struct IpxDims {
                                        //   tile, every class of a pass in ONE launch (ipx_plan_classes)
 };
 #ifndef IPX_LAT_MAX_JOBS
-#define IPX_LAT_MAX_JOBS 8192          // batches up to this size take the latency tier: 2 048 four-read tiles, two per SIMD (r04: 8 000 jobs 0.67 ms with the throughput kernels)
+#define IPX_LAT_MAX_JOBS 16384         // batches up to this size take the latency tier: 4 096 four-read tiles, four per SIMD (r04: 8 000 jobs 0.67 ms with the throughput kernels, 0.47 with these; 16 000: see DESIGN section 5)
 #endif
 // alignments per tile of the passes the wavefront kernels serve
 static inline int ipx_skew_na(const IpxDims &d) { return d.lat ? 2 * (64 / d.lat) : 16; }
