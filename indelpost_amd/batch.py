@@ -100,13 +100,15 @@ class JobTable:
         return cls(rc, ro, fc, fo, ref_id, gap_open, gap_ext)
 
     def desc(self):
-        """(addresses of reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len or 0, n_jobs, n_refs): what the library's
-        ipx_concat_tables takes per table.  Cached (the arrays are owned by the table and never reallocated)."""
-        d = getattr(self, "_desc", None)
+        """80 bytes = ten little-endian int64: addresses of reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len (or 0), then
+        n_jobs, n_refs -- what the library's ipx_concat_tables takes per table.  Cached (the arrays are owned by the table and never
+        reallocated); as BYTES, so that the descriptors of ten thousand tables are one b"".join away from the array the library reads."""
+        d = getattr(self, "_descb", None)
         if d is None:
-            d = self._desc = (self.reads.ctypes.data, self.read_off.ctypes.data, self.refs.ctypes.data, self.ref_off.ctypes.data,
-                              self.ref_id.ctypes.data, self.gap_open.ctypes.data, self.gap_ext.ctypes.data,
-                              0 if self.mask_len is None else self.mask_len.ctypes.data, len(self.ref_id), len(self.ref_off) - 1)
+            import struct
+            d = self._descb = struct.pack("<10q", self.reads.ctypes.data, self.read_off.ctypes.data, self.refs.ctypes.data, self.ref_off.ctypes.data,
+                                          self.ref_id.ctypes.data, self.gap_open.ctypes.data, self.gap_ext.ctypes.data,
+                                          0 if self.mask_len is None else self.mask_len.ctypes.data, len(self.ref_id), len(self.ref_off) - 1)
         return d
 
     @classmethod
@@ -118,13 +120,17 @@ class JobTable:
         staging: a callable (read_bytes, window_bytes, jobs, windows, with_mask) -> the eight arrays to fill (reads, read_off, refs,
         ref_off, ref_id, gap_open, gap_ext, mask_len or None), e.g. an aligner's page-locked, reused buffers
         (MultiStreamAligner.loci_staging); default: fresh arrays."""
-        import itertools
+        import operator
         tables = tables if isinstance(tables, (list, tuple)) else list(tables)
         n = len(tables)
         if not n:
             return cls(np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int8), np.zeros(1, np.int64), np.zeros(0, np.int32), 0, 0)
         L = _lib.lib()
-        desc = np.fromiter(itertools.chain.from_iterable([t.desc() for t in tables]), np.int64, 10 * n)
+        try:                                                       # (every table has been here before: one attribute read per table)
+            blob = b"".join(map(operator.attrgetter("_descb"), tables))
+        except (AttributeError, TypeError):
+            blob = b"".join([t.desc() for t in tables])
+        desc = np.frombuffer(blob, np.int64)
         tot = np.zeros(4, np.int64)
         all_mask = L.ipx_concat_sizes(desc.ctypes.data, n, tot.ctypes.data)
         rb, fb, nj, nr = (int(x) for x in tot)
