@@ -15,6 +15,8 @@ find_targets_by_ssw takes the alignment-independent filters (:244-249) as a mask
 down) is the whole function with the reference's signature, filters included, and find_by_smith_waterman_realn_many
 runs it for many loci in one GPU batch.
 """
+from bisect import bisect_left
+
 import numpy as np
 
 from .batch import JobTable, encode_dna
@@ -181,91 +183,220 @@ def find_targets_by_ssw(read_seqs, realign_mask, indel_seq, n_repeats, mut_ref_l
 # Parity: pinned by vectors from the reference's own function text run against duck-typed reads / contigs with
 # make_aligner / align bound to the oracle (oracle/gen_driver_golden.py, tests/golden/driver_cases.json).
 # =====================================================================================================================
-def findall_mismatches(read, end_trim=0):
-    """read["mismatches"] = [(pos, ref base, read base, quality)] over the read's mapped blocks (localn.pyx:71-136)"""
-    from .pileup import get_mapped_subreads, split
-    if read["is_reference_seq"]:
+def _block_table(read):
+    """The mapped blocks of one read, located the way localn.pyx:71-136 locates them.  Returns (seq, ref, front, blocks):
+    the read bases with the soft clips the reference cuts off (:86-101: only when the FIRST / LAST CIGAR token is a clip),
+    the number of bases cut in front, and per M/=/X run of the untrimmed CIGAR (utilities.pyx:221-240) the tuple
+    (genome start, span, kr, kf): kr / kf are the cut points utilities.pyx:429-503 (`split`, forward) arrives at on the trimmed
+    read and on ref_seq for that genome position -- the run's bases are data[kr - 1 : kr - 1 + span] when the read is well
+    formed.  The cut points come from cumulative (genome, read, reference) advances per token and one bisection per run,
+    not from three CIGAR walks per run."""
+    cigar = read["cigar_string"]
+    every = cigar_ptrn.findall(cigar)
+    seq, front, toks = read["read_seq"], 0, every
+    if "S" in cigar:
+        toks = read["cigar_list"]
+        if "S" in toks[0]:
+            toks, front = toks[1:], read["start_offset"]
+            seq = seq[front:]
+        if "S" in toks[-1]:
+            toks, seq = toks[:-1], seq[:-read["end_offset"]]
+    at, nr, nf = read["aln_start"] - 1, 0, 0
+    g_cum, r_cum, f_cum = [at], [0], [0]
+    for tok in toks:
+        op, n = tok[-1], int(tok[:-1])
+        if op == "N":
+            at += n
+        elif op == "I":
+            nr += n
+        elif op == "D":
+            at += n; nf += n
+        elif op not in "HP":
+            at += n; nr += n; nf += n
+        g_cum.append(at); r_cum.append(nr); f_cum.append(nf)
+    last = len(toks)
+    blocks, pos = [], read["aln_start"]
+    for tok in every:
+        op, n = tok[-1], int(tok[:-1])
+        if op in "M=X":
+            c = min(bisect_left(g_cum, pos), last)          # tokens the forward walk consumes before it has reached `pos`
+            over = g_cum[c] - pos
+            blocks.append((pos, n, r_cum[c] - over, f_cum[c] - over))
+            pos += n
+        elif op not in "ISHP":
+            pos += n
+    return seq, read["ref_seq"], front, blocks
+
+
+def _trimmed_quals(read):
+    """read_qual under the same clip trimming as the bases (localn.pyx:90-99)"""
+    quals, toks = read["read_qual"], read["cigar_list"]
+    if "S" in read["cigar_string"]:
+        if "S" in toks[0]:
+            toks, quals = toks[1:], quals[read["start_offset"]:]
+        if "S" in toks[-1]:
+            quals = quals[:-read["end_offset"]]
+    return quals
+
+
+def _mismatches_by_slicing(read, seq, ref, blocks, end_trim):
+    """a read whose cut points leave the sequences (hard clip in front of a soft clip, CIGAR and sequence lengths that disagree):
+    Python's slice rules decide what the reference compares -- negative and overlong indices included, and an empty left part
+    raises IndexError there as here (localn.pyx:120-122)"""
+    quals, out = _trimmed_quals(read), []
+    lo, hi = read["aln_start"] + end_trim, read["aln_end"] - end_trim
+    for start, span, kr, kf in blocks:
+        bases = seq[:kr][-1] + seq[kr:][:span - 1]
+        q = [quals[:kr][-1]] + list(quals[kr:][:span - 1])
+        under = ref[:kf][-1] + ref[kf:][:span - 1]
+        out += [(start + i, r.upper(), a, qq) for i, (r, a, qq) in enumerate(zip(under, bases, q)) if r != a and lo <= start + i <= hi]
+    return out
+
+
+def findall_mismatches_pileup(pileup, end_trim=0):
+    """read["mismatches"] = [(pos, reference base, read base, quality)] for every read of a pileup (localn.pyx:71-136 per read): the
+    mapped runs of ALL reads are compared in one pass over two byte buffers (read bases, reference bases under them); Python
+    objects are made for the differing bases only.  Returns the pileup."""
+    rows, seqs, refs = [], [], []                                  # rows: (read index, genome start, span, offset in seqs, offset in refs)
+    at_s = at_f = 0
+    held = []                                                      # reads compared in the buffers: (index, kr - 1 of each block)
+    for i, read in enumerate(pileup):
+        if read["is_reference_seq"]:
+            read["mismatches"] = []
+            continue
+        seq, ref, front, blocks = _block_table(read)
+        ls, lf = len(seq), len(ref)
+        plain = len(read["read_qual"]) == len(read["read_seq"]) and seq.isascii() and ref.isascii()
+        for start, span, kr, kf in blocks:
+            if not (1 <= kr and kr - 1 + span <= ls and 1 <= kf and kf - 1 + span <= lf):
+                plain = False
+        if not plain:
+            read["mismatches"] = _mismatches_by_slicing(read, seq, ref, blocks, end_trim)
+            continue
         read["mismatches"] = []
-        return read
-    aln_start, aln_end = read["aln_start"], read["aln_end"]
-    out = []
-    for start, end in get_mapped_subreads(read["cigar_string"], aln_start, aln_end):
-        span = end - start + 1
-        cigarstring = read["cigar_string"]
-        read_seq, quals = read["read_seq"], read["read_qual"]
-        if "S" in cigarstring:                                       # soft clips are cut off both the CIGAR and the read
-            cigarlst = read["cigar_list"]
-            if "S" in cigarlst[0]:
-                cigarlst = cigarlst[1:]
-                read_seq, quals = read_seq[read["start_offset"]:], quals[read["start_offset"]:]
-            if "S" in cigarlst[-1]:
-                cigarlst = cigarlst[:-1]
-                read_seq, quals = read_seq[:-read["end_offset"]], quals[:-read["end_offset"]]
-            cigarstring = "".join(cigarlst)
-        lt_seq, rt_seq = split(read_seq, cigarstring, start, aln_start, is_for_ref=False, reverse=False)
-        lt_qual, rt_qual = split(quals, cigarstring, start, aln_start, is_for_ref=False, reverse=False)
-        lt_ref, rt_ref = split(read["ref_seq"], cigarstring, start, aln_start, is_for_ref=True, reverse=False)
-        mapped_seq = lt_seq[-1] + rt_seq[:span - 1]
-        mapped_qual = [lt_qual[-1]] + list(rt_qual[:span - 1])
-        mapped_ref = lt_ref[-1] + rt_ref[:span - 1]
-        pos = start
-        for r, a, q in zip(mapped_ref, mapped_seq, mapped_qual):
-            if r != a and aln_start + end_trim <= pos <= aln_end - end_trim:
-                out.append((pos, r.upper(), a, q))
-            pos += 1
-    read["mismatches"] = out
-    return read
+        for start, span, kr, kf in blocks:
+            rows.append((i, start, span, at_s + kr - 1, at_f + kf - 1))
+        held.append(i)
+        seqs.append(seq); refs.append(ref)
+        at_s += ls; at_f += lf
+    if not rows:
+        return pileup
+    T = np.array(rows, np.int64)
+    who, start, span, in_s, in_f = T.T
+    first = np.zeros(len(T), np.int64)
+    np.cumsum(span[:-1], out=first[1:])
+    run = np.repeat(np.arange(len(T)), span)
+    step = np.arange(int(span.sum())) - first[run]
+    S = np.frombuffer("".join(seqs).encode("ascii"), np.uint8)
+    F = np.frombuffer("".join(refs).encode("ascii"), np.uint8)
+    a, r = S[in_s[run] + step], F[in_f[run] + step]
+    pos = start[run] + step
+    a0 = np.fromiter((pileup[i]["aln_start"] for i in held), np.int64, len(held))
+    a1 = np.fromiter((pileup[i]["aln_end"] for i in held), np.int64, len(held))
+    slot = np.searchsorted(np.asarray(held), who)[run]             # position of the run's read in `held`
+    hit = np.flatnonzero((a != r) & (a0[slot] + end_trim <= pos) & (pos <= a1[slot] - end_trim))
+    if not len(hit):
+        return pileup
+    in_read = (in_s[run] + step)[hit]                               # index into the concatenated trimmed reads
+    base = np.zeros(len(held) + 1, np.int64)
+    np.cumsum([len(x) for x in seqs], out=base[1:])
+    quals = {}
+    for h, p, rb, ab, ir in zip(slot[hit].tolist(), pos[hit].tolist(), r[hit].tolist(), a[hit].tolist(), in_read.tolist()):
+        read = pileup[held[h]]
+        q = quals.get(h)
+        if q is None:
+            q = quals[h] = _trimmed_quals(read)
+        read["mismatches"].append((p, chr(rb).upper(), chr(ab), q[ir - int(base[h])]))
+    return pileup
+
+
+def findall_mismatches(read, end_trim=0):
+    """localn.pyx:71-136, one read (same arguments, the read back)"""
+    return findall_mismatches_pileup([read], end_trim)[0]
+
+
+def worth_realn_mask(pileup, target_indel, qual_lim=23):
+    """is_worth_realn (localn.pyx:139-220) for every read of a pileup as one bool array: could a realignment of the read show the
+    target?  Clipped at the locus, or high-quality mismatches / indels over the target's span; not when the read ends inside
+    the target's repeat and equals the reference there.  The interval tests run over arrays; the target's equivalents -- which
+    the reference regenerates per read -- are made once; strings are compared only for reads that end inside the shiftable span.
+    Needs read["mismatches"] (findall_mismatches_pileup)."""
+    n = len(pileup)
+    verdict = np.zeros(n, bool)
+    if not n:
+        return verdict
+    col = lambda key: np.fromiter((r[key] for r in pileup), np.int64, n)
+    a0, a1 = col("aln_start"), col("aln_end")
+    cover = [r["covering_subread"] for r in pileup]
+    covered = np.fromiter((bool(c) for c in cover), bool, n)
+    at = target_indel.pos
+    cs = np.fromiter((c[0] if c else at for c in cover), np.int64, n)
+    ce = np.fromiter((c[1] if c else at + len(target_indel.ref) for c in cover), np.int64, n)
+    open_ = covered.copy() if target_indel.is_ins else np.ones(n, bool)          # :146-149: no covering piece and an insertion -> no
+    to_left, to_right = at - a0, a1 - at
+    lefty = (to_left < 0) | ((to_right >= 0) & (to_left <= to_right))             # :154-159
+    idx = np.flatnonzero(open_)
+    edge = np.zeros(n, np.int64)
+    for i in idx.tolist():                                                        # length of the CIGAR token at the read's near end
+        toks = pileup[i]["cigar_list"]
+        edge[i] = int((toks[0] if lefty[i] else toks[-1])[:-1])
+    clipped = open_ & (edge > 2) & np.where(lefty, (cs < a0) & (a0 <= ce), (cs <= a1) & (a1 < ce))     # :163-169
+    verdict[clipped] = True
+    open_ &= ~clipped
+    shifts = [v.pos for v in target_indel.generate_equivalents()]
+    lo, hi = min(shifts), max(shifts)
+    if lo < hi:                                                                   # :177-191
+        for i in np.flatnonzero(open_ & lefty & (lo < a0)).tolist():
+            k, r = hi - int(a0[i]), pileup[i]
+            if r["read_seq"][:k] == r["ref_seq"][:k]:
+                open_[i] = False
+        for i in np.flatnonzero(open_ & ~lefty & (a1 <= hi)).tolist():
+            k, r = int(a1[i]) - lo, pileup[i]
+            if r["read_seq"][-k:] == r["ref_seq"][-k:]:
+                open_[i] = False
+    idx = np.flatnonzero(open_).tolist()
+    who, where, q = [], [], []
+    for i in idx:
+        for m in pileup[i]["mismatches"]:
+            who.append(i); where.append(m[0]); q.append(m[3])
+    has = np.zeros(n, bool)
+    if who:
+        who, where, q = np.asarray(who), np.asarray(where, np.int64), np.asarray(q)
+        keep = (cs[who] <= where) & (where <= ce[who]) & (q > qual_lim)            # :171-175
+        who, where = who[keep], where[keep]
+        has[who] = True
+        far = np.iinfo(np.int64).max
+        lt_most, rt_most = np.full(n, far), np.full(n, -far)
+        np.minimum.at(lt_most, who, where)
+        np.maximum.at(rt_most, who, where)
+        w = np.flatnonzero(has)
+        near_end = np.where(lefty[w], np.abs(lt_most[w] - a0[w]) < 4, np.abs(rt_most[w] - a1[w]) < 4)
+        verdict[w] = near_end | covered[w]                                        # :194-208
+    for i in idx:                                                                 # :210-217: an indel of the read's own over the span
+        if not has[i]:
+            r = pileup[i]
+            lo_i, hi_i = cs[i], ce[i]
+            verdict[i] = any(lo_i <= v[0] <= hi_i for v in r["I"] + r["D"])
+    return verdict
 
 
 def is_worth_realn(read, target_indel, qual_lim=23):
-    """could a realignment of this read show the target?  (localn.pyx:139-220: clipped at the locus, high-quality mismatches
-    or indels over the target's span; not when the read ends inside the target's repeat and matches the reference there)"""
-    if read["covering_subread"]:
-        is_covered = True
-        covering_start, covering_end = read["covering_subread"][0], read["covering_subread"][1]
-    else:
-        is_covered = False
-        if target_indel.is_ins:
-            return False
-        covering_start = target_indel.pos
-        covering_end = covering_start + len(target_indel.ref)
-    to_left, to_right = target_indel.pos - read["aln_start"], read["aln_end"] - target_indel.pos
-    is_lefty = True if to_left < 0 else False if to_right < 0 else to_left <= to_right
-    start_cigar, end_cigar = read["cigar_list"][0], read["cigar_list"][-1]
-    if is_lefty and covering_start < read["aln_start"] <= covering_end and int(start_cigar[:-1]) > 2:
-        return True
-    if not is_lefty and covering_start <= read["aln_end"] < covering_end and int(end_cigar[:-1]) > 2:
-        return True
-    mismatches = [m for m in read["mismatches"] if covering_start <= m[0] <= covering_end and m[3] > qual_lim]
-    shiftable = [v.pos for v in target_indel.generate_equivalents()]
-    lt_pos, rt_pos = min(shiftable), max(shiftable)
-    if lt_pos < rt_pos:
-        if is_lefty:
-            if lt_pos < read["aln_start"]:
-                k = rt_pos - read["aln_start"]
-                if read["read_seq"][:k] == read["ref_seq"][:k]:
-                    return False
-        elif read["aln_end"] <= rt_pos:
-            k = read["aln_end"] - lt_pos
-            if read["read_seq"][-k:] == read["ref_seq"][-k:]:
-                return False
-    if mismatches:
-        if is_lefty:
-            at_end = abs(min(m[0] for m in mismatches) - read["aln_start"]) < 4
-        else:
-            at_end = abs(max(m[0] for m in mismatches) - read["aln_end"]) < 4
-        return True if at_end else is_covered
-    return bool([v for v in read["I"] + read["D"] if covering_start <= v[0] <= covering_end])
+    """localn.pyx:139-220, one read"""
+    return bool(worth_realn_mask([read], target_indel, qual_lim)[0])
 
 
-def _needs_realn(read, target_indel, mapq_lim):
-    """the filters of is_target_by_ssw that do not depend on the alignments (localn.pyx:243-249): None = already a target (left
-    as it is), False = not realigned (is_target set False), True = realign"""
-    if read["is_target"]:
-        return None
-    if read["is_reference_seq"] or read["mapq"] <= mapq_lim or not is_worth_realn(read, target_indel):
-        return False
-    return True
+def realn_plan(pileup, target_indel, mapq_lim):
+    """the filters of is_target_by_ssw that do not depend on the alignments (localn.pyx:243-249), for a whole pileup: an int8 array
+    with -1 = already a target (left as it is), 0 = not realigned (is_target becomes False), 1 = realign.  is_worth_realn is
+    evaluated (worth_realn_mask) only for the reads the cheaper tests let through, as the reference's `or` chain does."""
+    n = len(pileup)
+    plan = np.zeros(n, np.int8)
+    plan[[i for i, r in enumerate(pileup) if r["is_target"]]] = -1
+    ask = [i for i, r in enumerate(pileup) if not (r["is_target"] or r["is_reference_seq"] or r["mapq"] <= mapq_lim)]
+    if ask:
+        worth = worth_realn_mask([pileup[i] for i in ask], target_indel)
+        plan[np.asarray(ask)[worth]] = 1
+    return plan
 
 
 def is_target_by_ssw(read, target_indel, contig, mut_ref_lt, mut_ref_mid, mut_ref_rt, mut_aligner, ref_aligner, match_score,
@@ -273,8 +404,8 @@ def is_target_by_ssw(read, target_indel, contig, mut_ref_lt, mut_ref_mid, mut_re
                      mapped_base_cnt_thresh=40, allow_mismatches=10):
     """one read, the reference's signature (localn.pyx:223-291): two single alignments through the aligner objects.  The batched
     form is find_by_smith_waterman_realn below; this one exists for callers that hold a single read."""
-    need = _needs_realn(read, target_indel, mapq_lim)
-    if need is None:
+    need = realn_plan([read], target_indel, mapq_lim)[0]
+    if need < 0:
         return read
     if not need:
         read["is_target"] = False
@@ -322,16 +453,14 @@ def find_by_smith_waterman_realn_many(requests, device=0):
         mapq_lim = req[8] if len(req) > 8 else 1
         lt, mid, rt = contig.get_contig_seq(split=True)
         ref_ref, mut_ref = contig.get_reference_seq(), lt + mid + rt
-        pileup = [findall_mismatches(read) for read in pileup]
-        todo = []
-        for k, read in enumerate(pileup):
-            need = _needs_realn(read, target_indel, mapq_lim)
-            if need is False:
-                read["is_target"] = False
-            elif need:
-                todo.append(k)
-                seq = read["read_seq"]
-                R += [seq, seq]; W += [ref_ref, mut_ref]; GO += [go, len(seq)]; GE += [ge, ge]      # localn.pyx:253-255
+        pileup = findall_mismatches_pileup(list(pileup))
+        plan = realn_plan(pileup, target_indel, mapq_lim)
+        for k in np.flatnonzero(plan == 0).tolist():
+            pileup[k]["is_target"] = False
+        todo = np.flatnonzero(plan > 0).tolist()
+        for k in todo:
+            seq = pileup[k]["read_seq"]
+            R += [seq, seq]; W += [ref_ref, mut_ref]; GO += [go, len(seq)]; GE += [ge, ge]          # localn.pyx:253-255
         plans.append((target_indel, pileup, todo, lt, mid, rt))
     alns = align_many(R, W, GO, GE, requests[0][3], requests[0][4], device) if R else []
     at, out = 0, []
@@ -344,30 +473,32 @@ def find_by_smith_waterman_realn_many(requests, device=0):
 
 
 def parse_read_by_mut_aln(mut_aln, contig, read, indel_type):
-    """the read cut into left flank / indel / right flank along its alignment to the mutant contig (localn.pyx:475-539).
-    `contig` needs lt_consensus_seq, indel_seq, rt_consensus_seq."""
+    """the read cut into left flank / indel / right flank along its alignment to the mutant contig (localn.pyx:475-539; the
+    reference defines it and calls it nowhere).  `contig` needs lt_consensus_seq, indel_seq, rt_consensus_seq.  The three pieces
+    are worked out as index ranges first and cut once."""
     from .pileup import get_end_pos, split
-    lt_len, indel_len = len(contig.lt_consensus_seq), len(contig.indel_seq)
-    read_seq, read_qual = read["read_seq"], read["read_qual"]
-    ref_start, ref_end = mut_aln.reference_start, mut_aln.reference_end
-    aln_start, aln_end = mut_aln.read_start, mut_aln.read_end
-    lt_flank = mid_seq = rt_flank = ""
-    lt_qual, rt_qual = [], []
-    if ref_start <= lt_len:
-        lt_diff = lt_len - ref_start
-        cut = aln_start + lt_diff
-        lt_flank, lt_qual = read_seq[aln_start:cut], read_qual[aln_start:cut]
-        if indel_type == "I":
-            mid_seq = read_seq[cut:min(cut + indel_len, aln_end)]
+    flank, gap = len(contig.lt_consensus_seq), len(contig.indel_seq)
+    lo, hi = mut_aln.read_start, mut_aln.read_end
+    nothing = slice(0, 0)
+    lt = mid = rt = nothing
+    insertion = indel_type == "I"
+    if mut_aln.reference_start <= flank:                      # the alignment starts in the left flank: the read reaches the indel from the left
+        cut = lo + flank - mut_aln.reference_start
+        lt = slice(lo, cut)
+        if insertion:
+            mid = slice(cut, min(cut + gap, hi))
         else:
-            rt_flank, rt_qual = read_seq[cut:], read_qual[cut:]
-            del_pos = get_end_pos(read["read_start"] + aln_start, lt_flank, read["cigar_string"])
-            _, rt_ref = split(read["ref_seq"], read["cigar_string"], del_pos, read["aln_start"], is_for_ref=True, reverse=False)
-            read["del_pos"] = del_pos
-            read["del_seq"] = rt_ref[:indel_len]
-    if lt_len + indel_len <= ref_end and indel_type == "I":
-        rt_diff = ref_end - (lt_len + indel_len)
-        rt_flank, rt_qual = read_seq[aln_end - rt_diff:aln_end], read_qual[aln_end - rt_diff:aln_end]
-        mid_seq = read_seq[max(aln_start, aln_end - rt_diff - indel_len):aln_end - rt_diff]
-    read["lt_flank"], read["lt_qual"], read["indel_seq"], read["rt_flank"], read["rt_qual"] = lt_flank, lt_qual, mid_seq, rt_flank, rt_qual
+            rt = slice(cut, None)
+    if insertion and flank + gap <= mut_aln.reference_end:    # ... and ends in the right flank: the inserted bases are what lies before it
+        back = hi - (mut_aln.reference_end - flank - gap)
+        rt = slice(back, hi)
+        mid = slice(max(lo, back - gap), back)
+    seq, qual = read["read_seq"], read["read_qual"]
+    if lt is not nothing and not insertion:                   # :507-520: where the deletion sits on the genome and what it removed
+        where = get_end_pos(read["read_start"] + lo, seq[lt], read["cigar_string"])
+        read["del_pos"] = where
+        read["del_seq"] = split(read["ref_seq"], read["cigar_string"], where, read["aln_start"], is_for_ref=True, reverse=False)[1][:gap]
+    read["lt_flank"], read["indel_seq"], read["rt_flank"] = seq[lt], seq[mid], seq[rt]
+    read["lt_qual"] = qual[lt] if lt is not nothing else []
+    read["rt_qual"] = qual[rt] if rt is not nothing else []
     return read

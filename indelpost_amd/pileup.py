@@ -15,6 +15,8 @@ Parity: pinned by vectors from the reference's own function bodies -- split_ciga
 update_read_positions by oracle/gen_decoder_golden.py, update_read_info as a whole (through grid_search) by
 oracle/gen_driver_golden.py.
 """
+import numpy as np
+
 from .cigar import cigar_ptrn, findall_indels, make_insertion_first
 
 _NO_REF_MOVE = ("I", "H", "P")
@@ -718,24 +720,25 @@ def overhang_windows(target, intron):
 def filter_spurious_overhangs(target, intron, overhangs, match_score, mismatch_penalty, gap_open_penalty, gap_extension_penalty, device=0):
     """pileup.pyx:495-525 / 527-574, same arguments: the overhanging reads that are not spurious.  Both alignments of every
     non-reference overhang are one GPU batch; the read-level checks follow per read as in the reference."""
-    from .localn import findall_mismatches, is_worth_realn
+    from .localn import findall_mismatches_pileup, worth_realn_mask
     from .retarget import overhang_alignment_verdicts
     genome_ref, junction_ref = overhang_windows(target, intron)
     todo = [r for r in overhangs if not r["is_reference_seq"]]
     verdicts, _ = overhang_alignment_verdicts([r["read_seq"] for r in todo], genome_ref, junction_ref, match_score, mismatch_penalty,
                                               gap_open_penalty, gap_extension_penalty, device)
     lt_exon_end, rt_exon_start = intron[0] - 1, intron[1]
-    out = []
-    for read, v in zip(todo, verdicts):
+    keep, ask = set(), []
+    for k, (read, v) in enumerate(zip(todo, verdicts)):
         if v is False:
             continue
         # (the reference's expression: `read["D"] and read["I"]` is read["I"] when the read has deletions, else the empty list;
         #  the list of booleans is only tested for being non-empty)
-        within = [lt_exon_end < var[-1].pos < rt_exon_start for var in (read["D"] and read["I"])]
-        if within:
-            out.append(read)
-            continue
-        findall_mismatches(read)
-        if is_worth_realn(read, target):
-            out.append(read)
+        if [lt_exon_end < var[-1].pos < rt_exon_start for var in (read["D"] and read["I"])]:
+            keep.add(k)
+        else:
+            ask.append(k)
+    if ask:                                                # the read-level checks of every read still open, as arrays over those reads
+        sub = findall_mismatches_pileup([todo[k] for k in ask])
+        keep.update(np.asarray(ask)[worth_realn_mask(sub, target)].tolist())
+    out = [todo[k] for k in sorted(keep)]
     return out

@@ -109,3 +109,63 @@ def test_check_overhangs_default_splice_rate_matches_the_reference():
         assert got == c["expected"], (c["support"], got, c["expected"])
         between += 0.1 <= c["support"] < 0.2
     assert between >= 20
+
+
+def test_realignment_filters_match_the_reference_on_odd_cigars():
+    """findall_mismatches / is_worth_realn in their pileup-level array forms (localn.findall_mismatches_pileup, worth_realn_mask) and
+    as single-read calls against vectors from the reference's function text (oracle/gen_realn_filter_golden.py): 700 reads -- a soft clip
+    behind a hard clip, an insertion right behind the clip, =/X/P tokens, introns, lower-case reference bases, aln_end one off --
+    x two end trims, and 12 targets whose shiftable span reaches over read ends"""
+    import copy
+    import json
+    import os
+    from indelpost_amd import localn
+    with open(os.path.join(os.path.dirname(__file__), "golden", "realn_filter_cases.json")) as f:
+        fx = json.load(f)
+
+    class Shift:
+        def __init__(self, pos):
+            self.pos = pos
+
+    class Target:
+        def __init__(self, t):
+            self.pos, self.ref, self.alt, self.is_ins, self.n_made = t["pos"], t["ref"], t["alt"], len(t["alt"]) > len(t["ref"]), 0
+            self._shifts = t["shifts"]
+
+        def generate_equivalents(self):
+            self.n_made += 1
+            return [Shift(p) for p in self._shifts]
+
+    def reads():
+        out = copy.deepcopy([c["read"] for c in fx["reads"]])
+        for r in out:
+            r["covering_subread"] = tuple(r["covering_subread"]) if r["covering_subread"] else None
+        return out
+
+    as_lists = lambda ms: [list(m) for m in ms]
+    for trim in (0, 3):
+        pile = localn.findall_mismatches_pileup(reads(), trim)                 # the whole fixture as ONE pileup
+        singles = reads()
+        for r, one, case in zip(pile, singles, fx["reads"]):
+            assert as_lists(r["mismatches"]) == case["mismatches"][str(trim)], r["cigar_string"]
+            assert localn.findall_mismatches(one, trim) is one and one["mismatches"] == r["mismatches"]
+            assert all(type(m[0]) is int and type(m[3]) is int for m in r["mismatches"])
+    pile = localn.findall_mismatches_pileup(reads())
+    n_true = 0
+    for k, t in enumerate(fx["targets"]):
+        tgt = Target(t)
+        mask = localn.worth_realn_mask(pile, tgt, t["qual_lim"])
+        assert tgt.n_made == 1                                                 # (the reference regenerates the equivalents per read)
+        assert mask.tolist() == [c["worth"][k] for c in fx["reads"]]
+        n_true += int(mask.sum())
+        for j in range(k, len(pile), 12):
+            assert localn.is_worth_realn(pile[j], tgt, t["qual_lim"]) is fx["reads"][j]["worth"][k]
+    assert n_true > 1000
+    # the plan of a pileup: reads that are targets already stay, reference reads and low mapping qualities are not asked
+    for r, flag in zip(pile, range(len(pile))):
+        r["is_target"], r["mapq"] = flag % 7 == 0, 0 if flag % 5 == 0 else 40
+    tgt = Target(fx["targets"][0])
+    plan = localn.realn_plan(pile, tgt, 1)
+    worth = localn.worth_realn_mask(pile, tgt)
+    for r, p, w in zip(pile, plan.tolist(), worth.tolist()):
+        assert p == (-1 if r["is_target"] else int(not r["is_reference_seq"] and r["mapq"] > 1 and w))
