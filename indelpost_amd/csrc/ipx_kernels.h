@@ -1828,6 +1828,176 @@ IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBa
 //  spilled the callee-saved half of the body's registers to scratch -- 288-368 bytes per lane, a quarter of a gigabyte per launch, what the
 //  r03 profile showed as WRITE_SIZE -- and with the launches sized from the previous run's tile counts the per-class launches are as fast:
 //  config 4 55.8 with the tiers, 56.3 without; config 5 72.7 / 73.5.)
+// ------------------------------------------------------------------------------------------------
+// k_dp_wide<S, REV> (r04): the 16-bit passes (sw_sse2_word, ssw.c:410-586) of reads of 64 striped segments or more -- from 505 bp, up to
+// IPX_LONG_MAX_READ -- with gap_open > gap_ext, as ONE wavefront per read: the plain Gotoh recurrence as a wavefront over the lanes
+// (k_dp_skew: lane l owns the S consecutive rows l*S .. l*S+S-1 and works on column t - l at step t; what it needs from the lane above
+// arrives through whole-wavefront DPP shifts, one or two steps old; no lazy-F, see "Exactness" at k_dp_skew), on all 64 lanes, 64 * S rows,
+// S = 16 / 32 / 48 / 64 chosen per read (ROW SHIFT: the rows above the read stay 0).  Scores of reads this long leave the range halves
+// hold exactly (2 047), so the cells are unpacked 32-bit integers: H, E and the column saved at the lane's best in registers (3 * S + S
+// selectors: a whole SIMD's register file for one wave at S = 64), no saturation needed while readLen * max(mat) <= 32 767 (checked on the
+// host: the reference's _mm_adds_epi16 then never saturates either).  The score of a cell is ONE v_perm_b32: the scores of the lane's
+// window letter against A, C, G, T sit in bytes 1 and 3 of two table words, and the selector of a row picks its byte and the SIGN selectors
+// (8..11: bit 15 / 31 of either source replicated) for the three bytes above it; rows above or below the read and the letter N select the
+// constant 0 (the selector profile's condition, mat[.][N] = 0).  The window is staged in LDS once per read, in processing order, with
+// IPX_WIDE_PAD letters "5" (no column: scores -128, nothing is recorded there) on either side, so that lane l simply reads byte t - l.
+// k_dp_long -- the reference's loops transcribed, state in global memory -- keeps the jobs with gap_open <= gap_ext and the 8-bit passes
+// of reads beyond 1 008 bp: 0.3 s per tile of four 2 kb reads against 20 kb there, ~10 ms per read here.
+// ------------------------------------------------------------------------------------------------
+#define IPX_WIDE_PAD 64
+#define IPX_WIDE_MAX_SCORE 32767                 // readLen * max(mat) beyond it: the reference's 16-bit adds could saturate -- k_dp_long's business
+static inline int ipx_wide_lds_bytes(int maxcols) { return 64 + ((maxcols + 2 * IPX_WIDE_PAD + 8 + 3) & ~3); }
+IPX_HD constexpr int ipx_wide_bucket(int rows) { return rows <= 64 * 16 ? 16 : (rows <= 64 * 32 ? 32 : (rows <= 64 * 48 ? 48 : 64)); }
+IPX_DEV int imax(int a, int b) { return a > b ? a : b; }
+template <int S, bool REV>
+IPX_KERNEL_WAVE_OCC(S <= 16 ? 2 : 1) void k_dp_wide(IpxBatch b, IpxPlan p, int maxcols, int pass)
+{
+    const int l = lane_id();
+    unsigned char *lds = IPX_LDS_BASE;
+    uint32_t *tab = (uint32_t *)lds;                                   // [6 window letters][2]: scores against A, C | G, T in bytes 1 and 3
+    unsigned char *win = lds + 64;
+    if (l < 12) {
+        const int c = l >> 1, a = 2 * (l & 1);
+        uint32_t w = 0x80008000u;                                      // letter 5 (no column): -128 against everything
+        if (c < 5) w = ((uint32_t)(uint8_t)b.mat[c * 5 + a] << 8) | ((uint32_t)(uint8_t)b.mat[c * 5 + a + 1] << 24);
+        tab[l] = w;
+    }
+    uint32_t *maxcol = b.maxcol_scratch + (size_t)IPX_BID * (size_t)(8 * maxcols);
+    const int cls = IPX_MAX_SEG;
+    const uint32_t njobs = p.cls_off[cls + 1] - p.cls_off[cls];
+    for (uint32_t want = (uint32_t)IPX_BID; want < njobs; want += (uint32_t)IPX_GDIM) {
+        const int64_t job = (int64_t)p.perm[p.cls_off[cls] + want];
+        const int rid = b.ref_id[job];
+        const int8_t *rd = b.reads + b.read_off[job];
+        const int8_t *rf = b.refs_packed + b.refp_off[rid];
+        const int gO = b.gap_open[job], gE = b.gap_ext[job];
+        int L, ncol, score1 = 0, rend1 = -1;
+        if (!REV) { L = (int)(b.read_off[job + 1] - b.read_off[job]); ncol = b.ref_len[rid]; }
+        else {
+            const IpxResult r = b.res[job];
+            L = r.read_end1 + 1; if (L < 0) L = 0;
+            ncol = r.ref_end1 + 1; if (ncol < 0) ncol = 0;
+            score1 = r.score1; rend1 = r.read_end1;
+        }
+        const int rows = 8 * ((L + 7) >> 3);                           // the reference's padded row count (ssw.c:396-398)
+        if (ipx_wide_bucket(rows) != S) continue;                      // (another instantiation's read; uniform over the wave)
+        if (gO <= gE || rows > 64 * S || ncol > maxcols) { if (l == 0) atomic_or_u32(b.status, IPX_STATUS_INTERNAL); continue; }   // (host-side routing error)
+        const int dl = 64 * S - rows;                                  // rows the read is shifted down by
+        IPX_SYNC();
+        for (int k = l; k < ncol + 2 * IPX_WIDE_PAD + 8; k += 64) {
+            const int c = k - IPX_WIDE_PAD;
+            win[k] = (uint8_t)((c >= 0 && c < ncol) ? rf[REV ? ncol - 1 - c : c] : 5);
+        }
+        uint32_t SEL[S];
+        IPX_UNROLL
+        for (int j = 0; j < S; ++j) {
+            const int r = j + l * S - dl;
+            uint32_t sel = 0x0c0c0c0cu;
+            if (r >= 0 && r < L) {
+                const unsigned a = (unsigned)(int)load_stream_i8(rd + (REV ? L - 1 - r : r));
+                if (a < 4u) sel = a == 0 ? 0x08080801u : (a == 1 ? 0x09090903u : (a == 2 ? 0x0a0a0a05u : 0x0b0b0b07u));
+            }
+            SEL[j] = sel;
+        }
+        int H[S], E[S], HM[S];
+        IPX_UNROLL
+        for (int j = 0; j < S; ++j) { H[j] = 0; E[j] = 0; HM[j] = 0; }
+        int Hl_cur = 0, Hl_old = 0, vFend = 0, pm = 0, lbest = 0, lcol = 0;
+        IPX_SYNC();
+        int let = win[IPX_WIDE_PAD - l], letn = win[IPX_WIDE_PAD + 1 - l];
+        uint32_t X = tab[2 * let], Y = tab[2 * let + 1];
+        const int TT = ncol > 0 ? ncol + 63 : 0;
+        int tend = -1;
+        for (int t = 0; t < TT && (tend < 0 || t <= tend); ++t) {
+            const uint32_t Xc = X, Yc = Y;
+            const bool valid = let < 5;
+            // (the next step's table words and the letter after it: requested before the stripe, arrived after it)
+            let = letn;
+            X = tab[2 * let]; Y = tab[2 * let + 1];
+            letn = win[IPX_WIDE_PAD + t + 2 - l];
+            int vH = (int)xl_wave_shr1((uint32_t)Hl_old);
+            int vF = (int)xl_wave_shr1((uint32_t)vFend);
+            int cmx = (int)xl_wave_shr1((uint32_t)pm);
+            IPX_UNROLL
+            for (int j = 0; j < S; ++j) {
+                int h = vH + (int)pk_perm(Yc, Xc, SEL[j]);
+                h = imax(imax(h, E[j]), vF);
+                vH = H[j];
+                H[j] = h;
+                cmx = imax(cmx, h);
+                const int tt = h - gO;
+                E[j] = imax(imax(E[j] - gE, tt), 0);
+                vF = imax(imax(vF - gE, tt), 0);
+            }
+            vFend = vF;
+            Hl_old = Hl_cur;
+            Hl_cur = H[S - 1];
+            pm = cmx;
+            if (!REV && l == 63 && t >= 63) store_global_u32(maxcol + (t - 63), (uint32_t)pm);   // column t-63 is complete
+            const bool better = valid && cmx > lbest;
+            if (better) lbest = cmx;
+            const bool rec = REV ? (better && cmx == score1) : better;
+            if (xl_any(rec)) {
+                if (rec) lcol = t - l;
+                IPX_UNROLL
+                for (int j = 0; j < S; ++j) HM[j] = rec ? H[j] : HM[j];
+            }
+            if (REV && tend < 0 && xl_any(lbest == score1 && lbest > 0)) tend = t + 63;   // every lane has been through that column 63 steps on
+        }
+        // ---- finalisation (dp_skew_tile's, one read) ----
+        IPX_SYNC();
+        IPX_COMPILER_FENCE();
+        const uint32_t bestA = group_umax<64>((uint32_t)lbest);
+        const bool isb = (uint32_t)lbest == bestA;
+        const uint32_t cminA = group_umin<64>(isb ? (uint32_t)lcol : 0x7FFFFFFFu);
+        const bool mine = isb && (uint32_t)lcol == cminA;
+        uint32_t rmin = 0x7FFFFFFFu;
+        IPX_UNROLL
+        for (int j = S - 1; j >= 0; --j)
+            if (mine && (uint32_t)HM[j] == bestA) rmin = (uint32_t)(j + l * S);
+        rmin = group_umin<64>(rmin);
+        int rrow = (int)rmin - dl;
+        if (rrow < 0) rrow = 0;
+        int end_read = L - 1;
+        if (rrow < end_read) end_read = rrow;
+        const int eref = bestA == 0 ? 0 : (REV ? ncol - 1 - (int)cminA : (int)cminA);
+        if (REV && l == 0 && bestA != (uint32_t)score1) atomic_or_u32(b.status, IPX_STATUS_INTERNAL);   // (cannot happen: the forward optimum lies inside the prefix rectangle)
+        int key = -1;
+        if (!REV) {
+            const int maskLen = mask_len_of(b, job, L);
+            int edgeL = eref - maskLen; if (edgeL < 0) edgeL = 0;
+            int edgeR = eref + maskLen; if (edgeR > ncol) edgeR = ncol;
+            uint32_t v2 = 0, c2 = 0;                                   // second best outside the mask (ssw.c:568-581): first strict maximum in scan order
+            for (int col = l; col < ncol; col += 64)
+                if (col < edgeL || col >= edgeR) {
+                    const uint32_t v = load_global_u32(maxcol + col);
+                    if (v > v2) { v2 = v; c2 = (uint32_t)col; }
+                }
+            const uint32_t v2A = group_umax<64>(v2);
+            const uint32_t c2A = group_umin<64>(v2 == v2A ? c2 : 0x7FFFFFFFu);
+            if (l == 0) {
+                IpxResult r = b.res[job];
+                r.score1 = (uint16_t)bestA;
+                r.ref_end1 = eref;
+                r.read_end1 = end_read;
+                r.read_begin1 = -1;
+                r.score2 = (uint16_t)(maskLen >= 15 ? v2A : 0u);                                   // ssw.c:864-870
+                r.ref_end2 = maskLen >= 15 ? (int)c2A : -1;
+                r.mode = pass == IPX_PASS_WORD_FIRST ? IPX_MODE_WORD_UNPROVEN : IPX_MODE_WORD;
+                b.res[job] = r;
+                key = next_pass_key(b, r, L, false);
+            }
+        } else if (l == 0) {
+            IpxResult r = b.res[job];
+            r.ref_begin1 = eref;                                                                   // ssw.c:885
+            r.read_begin1 = rend1 - end_read;                                                      // ssw.c:886
+            if ((uint32_t)score1 > bestA) r.flag = 2;                                              // ssw.c:888-891
+            b.res[job] = r;
+        }
+        if (!REV) plan_note(b, key);
+    }
+}
+
 #if IPX_AUX_KERNELS
 // ------------------------------------------------------------------------------------------------
 // k_dp_long<W, REV>: sw_sse2_byte (W = 16, ssw.c:197-384) / sw_sse2_word (W = 8, ssw.c:410-586) for reads too long for the
@@ -1862,7 +2032,7 @@ IPX_DEV int group16_max_i(int x)
     return x;
 }
 template <int W, bool REV>
-IPX_KERNEL_WAVE void k_dp_long(IpxBatch b, IpxPlan p, int na, int maxcols, int pass, unsigned char *state, int64_t state_stride)
+IPX_KERNEL_WAVE void k_dp_long(IpxBatch b, IpxPlan p, int na, int maxcols, int pass, unsigned char *state, int64_t state_stride, int halves)
 {
     constexpr bool BYTE = W == 16;
     const int lane = lane_id();
@@ -1879,6 +2049,7 @@ IPX_KERNEL_WAVE void k_dp_long(IpxBatch b, IpxPlan p, int na, int maxcols, int p
     const int bias = b.bias;
 
     for (int half = 0; half < 2; ++half) {
+        if (!((halves >> half) & 1)) continue;                         // (bit 0: the fast-gap class, bit 1: the slow-gap class; r04: k_dp_wide may have the first)
         const int cls = IPX_MAX_SEG + half * IPX_SLOW_BASE;
         const uint32_t ntile = p.tile_off[cls + 1] - p.tile_off[cls];
         const uint32_t nsub = (uint32_t)((na + 3) / 4);
@@ -3614,7 +3785,11 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 // the stepped 8-bit passes of classes 1..16 in one launch (k_dp_pass_tier)
 #define IPX_PASS_TIER_DEFINE(REV) template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #define IPX_PASS_TIER_EXTERN(REV) extern template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
+#define IPX_WIDE_FAMILY(X) X(16, false) X(16, true) X(32, false) X(32, true) X(48, false) X(48, true) X(64, false) X(64, true)
+#define IPX_WIDE_DEFINE(S, REV) template __global__ void k_dp_wide<S, REV>(IpxBatch, IpxPlan, int, int);
+#define IPX_WIDE_EXTERN(S, REV) extern template __global__ void k_dp_wide<S, REV>(IpxBatch, IpxPlan, int, int);
 #if defined(IPX_EXTERN_KERNELS)
+IPX_WIDE_FAMILY(IPX_WIDE_EXTERN)
 IPX_DP_UNIT_X(IPX_LAT_EXTERN)
 IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)

@@ -129,6 +129,7 @@ static inline bool ipx_low2_ok(const IpxBatch &b, const IpxDims &d, int routing)
 #define IPX_NUM_KEYS (IPX_K_NUM * 256)
 #define IPX_SUB_GENERIC 140
 #define IPX_SUB_LONG 141      // k_dp_long (reads of 64 segments or more)
+#define IPX_SUB_WIDE 142      // k_dp_wide (r04: the 16-bit passes of those reads with gap_open > gap_ext)
 #define IPX_SUB_TIER 150      // timing sub-key of tier t: IPX_SUB_TIER + t (wavefront tiers 0..3; 8 = the stepped 8-bit tier, k_dp_pass_tier)
 
 template <class BE, int W, bool REV, int STAGE>
@@ -213,6 +214,7 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
 {
     uint64_t exact[2] = {0, 0};                                   // classes with their own launch: [0] fast, [1] slow gaps
     bool rest = false, lng = false;                               // anything the exact launches do not cover?  any read of 64 segments or more?
+    int lng_halves = 0;                                           // ... bit 0: among the fast-gap classes, bit 1: among the slow-gap ones
     int need = 0;                                                 // ... and its largest segLen
     for (int half = 0; half < 2; ++half) {
         if (!((halves >> half) & 1)) { exact[half] = ~0ull; continue; }       // (not ours: the sweep below skips these tiles too)
@@ -221,7 +223,7 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
         if (from > 0) exact[half] |= (from >= 64 ? ~0ull : ((1ull << from) - 1ull));   // (served elsewhere: the sweep skips them)
         int top = -1;
         for (int c = 0; c <= IPX_MAX_SEG; ++c) if (hs[c]) top = c;
-        if (top >= IPX_MAX_SEG) lng = true;
+        if (top >= IPX_MAX_SEG) { lng = true; lng_halves |= 1 << half; }
         uint32_t tier = 0;                                        // classes that share the tier launch (k_dp_pass_tier) instead of having their own
         if constexpr (W == 16 && STAGE == IPX_STAGE_EXACT) {
             if (half == 0 && ipx_perm_profile_ok(b.mat, routing) && !(routing & IPX_ROUTE_NO_TIERS)) {
@@ -251,9 +253,26 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
     if (lng && ws.long_state) {
         // reads of 64 segments or more (over 512 bp in the 16-bit passes, over 1 024 bp in the 8-bit passes): the long-read kernel
         const int tile = na > 0 ? na : 128 / W;
+        int mine = lng_halves;                                    // bit 0: the fast-gap long class, bit 1: the slow-gap one
+        if constexpr (W == 8 && STAGE == IPX_STAGE_EXACT) {
+            // r04: the 16-bit passes of the fast-gap long class as one wavefront per read (k_dp_wide), where its unsaturated 32-bit cells
+            // are the reference's: selector profile (mat[.][N] = 0) and no score beyond 32 767
+            if ((mine & 1) && !(routing & IPX_ROUTE_NO_WIDE) && ipx_perm_profile_ok(b.mat, routing) &&
+                (int64_t)IPX_LONG_MAX_READ * b.max_match <= IPX_WIDE_MAX_SCORE && maxcols <= 32768) {
+                int64_t g = (int64_t)be.dp_grid(pass, IPX_MAX_SEG) * tile;
+                if (g > be.dp_grid()) g = be.dp_grid();
+                if (g < 1) g = 1;
+                const int lds = ipx_wide_lds_bytes(maxcols);
+                be.launch(IPX_KEY(kclass, IPX_SUB_WIDE), k_dp_wide<16, REV>, (int)g, 64, lds, b, p, maxcols, pass);
+                be.launch(IPX_KEY(kclass, IPX_SUB_WIDE), k_dp_wide<32, REV>, (int)g, 64, lds, b, p, maxcols, pass);
+                be.launch(IPX_KEY(kclass, IPX_SUB_WIDE), k_dp_wide<48, REV>, (int)g, 64, lds, b, p, maxcols, pass);
+                be.launch(IPX_KEY(kclass, IPX_SUB_WIDE), k_dp_wide<64, REV>, (int)g, 64, lds, b, p, maxcols, pass);
+                mine &= ~1;
+            }
+        }
         int grid = be.dp_grid();
         if (grid > ws.long_blocks) grid = ws.long_blocks;
-        be.launch(IPX_KEY(kclass, IPX_SUB_LONG), k_dp_long<W, REV>, grid, 64, 64, b, p, tile, maxcols, pass, ws.long_state, ws.long_stride);
+        if (mine) be.launch(IPX_KEY(kclass, IPX_SUB_LONG), k_dp_long<W, REV>, grid, 64, 64, b, p, tile, maxcols, pass, ws.long_state, ws.long_stride, mine);
     }
     if (!rest) return;
     // the sweep kernel keeps segLen registers for its largest class: size it for the largest class it

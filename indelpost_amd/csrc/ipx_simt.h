@@ -86,7 +86,7 @@ IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return (v >> o
 // (low | high) 16 bits of a and of b -> packed pair (lo half from a, hi half from b)
 IPX_DEV pk16 pk_lo16_pair(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
 IPX_DEV pk16 pk_hi16_pair(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
-// v_perm_b32: result byte i = byte sel[i] of the 8-byte table {hi:lo} (0..3 = lo, 4..7 = hi), 0x0c = constant 0
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte table {hi:lo} (0..3 = lo, 4..7 = hi), 0x0c = constant 0, 8..11 = 0x00 / 0xff by bit 15 / 31 / 47 / 63
 IPX_DEV uint32_t pk_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 {
     const uint64_t t = ((uint64_t)hi << 32) | lo;
@@ -96,6 +96,7 @@ IPX_DEV uint32_t pk_perm(uint32_t hi, uint32_t lo, uint32_t sel)
         uint32_t v;
         if (k < 8u) v = (uint32_t)(t >> (8 * k)) & 0xFFu;
         else if (k == 0x0cu) v = 0u;
+        else if (k >= 8u && k <= 11u) v = ((t >> (16 * (k - 8u) + 15)) & 1u) ? 0xFFu : 0u;   // sign of byte 1 / 3 / 5 / 7, replicated
         else { fprintf(stderr, "emu: pk_perm selector %#x not modelled\n", k); abort(); }
         r |= v << (8 * i);
     }

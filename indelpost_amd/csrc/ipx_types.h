@@ -93,6 +93,7 @@ enum {
     IPX_ROUTE_NO_LAT_PROOF = 131072,      // the latency tier keeps the lane-per-read overflow proof (k_prove_overflow) instead of k_prove_overflow_diag
     IPX_ROUTE_NO_SPECULATE = 524288,      // the latency tier launches every pass, also those the previous run found empty
     IPX_ROUTE_TEST_SKIP_ALL = 1048576 * 2, // (testing) every dynamic pass of the latency tier is predicted empty: the guard must notice and the run be repeated
+    IPX_ROUTE_NO_WIDE = 262144,           // reads of 64 segments or more take the transcribed loops (k_dp_long) in the 16-bit passes too (default: one wavefront per read, k_dp_wide)
     IPX_ROUTE_FORCE_LAT = 65536,          // (testing) the latency tier whatever the batch size, where its other conditions hold
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };

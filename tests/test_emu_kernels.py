@@ -449,6 +449,48 @@ def test_emu_long_reads_take_the_long_read_kernel(emu, oracle_mod, port):
         assert a.status == 0
         _compare(res, [(r, w, o_, e_) for r, o_, e_ in zip(reads, go, ge)], port, oracle_mod.dna_matrix(ms, mm))
         assert any(k % 256 == 141 for k in a.launches)                    # IPX_SUB_LONG: the long-read kernel ran
+        assert any(k % 256 == 142 for k in a.launches)                    # IPX_SUB_WIDE: ... and, for the 16-bit passes under fast gaps, k_dp_wide
+
+
+def test_emu_long_reads_one_wavefront_per_read(emu, oracle_mod, port):
+    """r04, k_dp_wide<16 / 32 / 48 / 64>: the 16-bit passes of reads from 505 bp under gap_open > gap_ext as one wavefront per read --
+    64 lanes x S consecutive rows, 32-bit cells, the window staged in LDS in processing order.  Reads of every bucket (505..4 000 bp), with
+    an insertion, a deletion, N, a read longer than its window, a window of 70 columns (shorter than the wavefront's 63 steps of lead-in),
+    a read that matches nowhere; forward and reverse, every field and CIGAR against the oracle; the same jobs through the transcribed loops
+    (ROUTE_NO_WIDE) give the same records."""
+    from indelpost_amd.batch import ROUTE_NO_WIDE
+    rng = np.random.default_rng(505)
+    refs = [rng.integers(0, 4, n).astype(np.int8) for n in (900, 70, 2300)]
+    reads, rid, go, ge = [], [], [], []
+    for i, ln in enumerate([505, 512, 1000, 1024, 1030, 1700, 2047, 2100, 3000, 3080, 4000, 4096, 640, 777]):
+        k = (0, 2, 0, 2, 1, 2, 0, 2, 0, 2, 2, 0, 1, 0)[i]
+        w = refs[k]
+        src = np.resize(w[int(rng.integers(0, 40)):], ln).copy() if i != 12 else rng.integers(0, 4, ln).astype(np.int8)
+        m = rng.random(ln) < 0.03
+        src[m] = rng.integers(0, 5, int(m.sum()))                         # (5 letters: a few N)
+        if i % 3 == 0:
+            src = np.concatenate([src[:ln // 2], src[ln // 2 + 7:]])
+        if i % 3 == 1:
+            src = np.concatenate([src[:ln // 3], rng.integers(0, 4, 9).astype(np.int8), src[ln // 3:]])[:4096]
+        reads.append(src); rid.append(k)
+        g = [(3, 1), (5, 0), (4, 1), (6, 2), (2, 1)][i % 5]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+    for ms, mm in ((3, 2), (1, 3)):
+        a = emu(0, ms, mm)
+        res = a.align(jobs)
+        assert a.status == 0
+        _compare(res, [(r, refs[k], o_, e_) for r, k, o_, e_ in zip(reads, rid, go, ge)], port, oracle_mod.dna_matrix(ms, mm))
+        assert sum(n for k, n in a.launches.items() if k % 256 == 142) >= 8     # four buckets, forward and reverse
+        assert not any(k % 256 == 141 and k // 256 in (K_WORD_FIRST, K_WORD_FWD, K_WORD_REV) for k in a.launches)
+    # (the transcribed loops are slow in the emulator -- ballots per lazy-F step: three of the shorter jobs, one scoring)
+    few = [0, 1, 4]
+    sub = JobTable.from_sequences([reads[i] for i in few], refs, [rid[i] for i in few], [go[i] for i in few], [ge[i] for i in few], encoded=True)
+    a, b = emu(0, 3, 2), emu(0, 3, 2)
+    b.set_routing(ROUTE_NO_WIDE)
+    res, res2 = a.align(sub), b.align(sub)
+    assert a.status == 0 and b.status == 0 and not any(k % 256 == 142 for k in b.launches) and any(k % 256 == 142 for k in a.launches)
+    assert res2.records.tobytes() == res.records.tobytes() and res2.cigar_pool.tobytes() == res.cigar_pool.tobytes()
 
 
 def test_emu_anti_diagonal_traceback_tiers(emu, oracle_mod, port):

@@ -254,6 +254,53 @@ def test_gpu_reads_of_kilobases_vs_windows_of_tens_of_kilobases(gpu, oracle_mod,
     assert int(np.diff(jobs.read_off).max()) >= 4000 and (res.records["read_end1"] > 2000).any()
 
 
+def test_gpu_kilobase_reads_one_wavefront_per_read(gpu, oracle_mod, capfd):
+    """r04, k_dp_wide: the 16-bit passes of reads from 505 bp under gap_open > gap_ext as ONE wavefront per read (64 lanes x 16 / 32 / 48 / 64
+    rows, 32-bit cells).  Every bucket, 505-4 096 bp against windows of 70-12 000 bp, insertions, deletions, N, noise, three scorings, six
+    gap-penalty pairs -- every field and CIGAR against the compiled reference; then the same table through the transcribed loops
+    (ROUTE_NO_WIDE): equal digests, and the wavefront form at least 20 times faster in the 16-bit passes (r03 verdict, task 8)."""
+    from indelpost_amd.batch import ROUTE_NO_WIDE
+    rng = np.random.default_rng(50505)
+    refs = [rng.integers(0, 4, n).astype(np.int8) for n in (900, 70, 5000, 12000)]
+    reads, rid, go, ge = [], [], [], []
+    lens = [505, 511, 512, 520, 1000, 1024, 1025, 1030, 1700, 2047, 2048, 2049, 2100, 3000, 3072, 3073, 3080, 4000, 4095, 4096]
+    for i in range(80):
+        ln = lens[i % len(lens)]
+        k = (0, 2, 3, 2, 1, 3)[i % 6]
+        w = refs[k]
+        src = np.resize(w[int(rng.integers(0, max(1, len(w) - 60))):], ln).copy() if i % 13 != 12 else rng.integers(0, 4, ln).astype(np.int8)
+        m = rng.random(ln) < (0.0, 0.01, 0.04)[i % 3]
+        src[m] = rng.integers(0, 5, int(m.sum()))
+        if i % 4 == 1:
+            cut = int(rng.integers(20, ln - 60))
+            src = np.concatenate([src[:cut], src[cut + int(rng.integers(1, 40)):]])
+        if i % 4 == 2:
+            cut = int(rng.integers(20, ln - 20))
+            src = np.concatenate([src[:cut], rng.integers(0, 4, int(rng.integers(1, 30))).astype(np.int8), src[cut:]])[:4096]
+        reads.append(src); rid.append(k)
+        g = [(3, 1), (5, 0), (4, 1), (6, 2), (2, 1), (9, 3)][i % 6]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, refs, rid, go, ge, encoded=True)
+    for scoring in ((3, 2), (1, 3), (7, 4)):
+        gpu.set_routing(0)
+        res = _check_all(gpu, oracle_mod, jobs, scoring, capfd)
+    gpu.set_profiling(True)
+    res = gpu.align(jobs)
+    wide = {k: v for k, v in gpu.kernel_times().items() if k.endswith("_kb_wavefront")}
+    assert {"dp_word_first_kb_wavefront", "dp_word_rev_kb_wavefront"} <= set(wide)
+    assert not [k for k in gpu.kernel_times() if k.startswith("dp_word") and k.endswith("_kb_loops")]      # (no job with gap_open <= gap_ext here)
+    gpu.set_profiling(False); gpu.set_profiling(True)
+    gpu.set_routing(ROUTE_NO_WIDE)
+    res2 = gpu.align(jobs)
+    loops = {k: v for k, v in gpu.kernel_times().items() if k.startswith("dp_word") and k.endswith("_kb_loops")}
+    gpu.set_profiling(False)
+    gpu.set_routing(0)
+    assert res2.digest() == res.digest()
+    t_wide, t_loops = sum(v[0] for v in wide.values()), sum(v[0] for v in loops.values())
+    print("16-bit passes of 80 reads of 505-4096 bp: wavefront per read %.2f ms, transcribed loops %.2f ms" % (t_wide, t_loops))
+    assert t_loops > 20 * t_wide
+
+
 def test_gpu_windows_of_tens_of_kilobases(gpu, oracle_mod, capfd):
     """windows up to 32 000 bp (r03; the limit was 4 096): short reads against 20 kb windows, among them reads that bridge a deletion of
     more than a kilobase under gap extension 0 -- their traceback band grows past what LDS holds and lives in the global scratch"""
