@@ -151,6 +151,7 @@ struct IpxRunReset {
 };
 IPX_KERNEL void k_init(IpxBatch b, IpxRunReset z)
 {
+    IPX_RAISE_PRIO(b);
     for (int64_t i = (int64_t)IPX_BID * IPX_BDIM + IPX_TID; i < b.n_jobs; i += (int64_t)IPX_GDIM * IPX_BDIM) {
         IpxResult r;
         r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
@@ -284,6 +285,7 @@ IPX_DEV void wave_class_slots(uint32_t *counter, const int (&cls)[IPX_PLAN_ROUND
 // pass whose jobs come straight from k_init (16-bit only profiles)
 IPX_KERNEL void k_plan_count(IpxBatch b, int pass)
 {
+    IPX_RAISE_PRIO(b);
     const int64_t chunk = (int64_t)IPX_BDIM * IPX_PLAN_ROUNDS, stride = (int64_t)IPX_GDIM * chunk;
     const int64_t iters = (b.n_jobs + stride - 1) / stride;
     uint32_t *row = b.plan_counts + (size_t)pass * (2 * IPX_NUM_CLASSES);
@@ -304,6 +306,7 @@ IPX_KERNEL void k_plan_count(IpxBatch b, int pass)
 // also publishes them for the DP kernels of the pass.
 IPX_KERNEL void k_plan_scatter(IpxBatch b, IpxPlan p, int pass, int na)
 {
+    IPX_RAISE_PRIO(b);
     uint32_t *cls_off = (uint32_t *)IPX_LDS_BASE, *tile_off = cls_off + IPX_NUM_CLASSES + 1;
     const int lane = lane_id();
     {
@@ -1356,6 +1359,7 @@ IPX_DEV void dp_pass_tier_walk(uint32_t set_mask, const IpxBatch &b, const IpxPl
 template <int W, int SLO, int SHI, bool REV, int STAGE>
 IPX_KERNEL_WAVE_OCC(REV ? ipx_dp_perm_waves(SHI) : 1) void k_dp_pass_tier(IpxBatch b, IpxPlan p, uint32_t set_mask, int maxcols, int pass)
 {
+    IPX_RAISE_PRIO(b);
     dp_pass_tier_walk<W, SLO, SHI, REV, STAGE>(set_mask, b, p, maxcols, pass, 0u);
 }
 
@@ -2333,6 +2337,7 @@ IPX_DEV bool prove_band(const IpxBatch &b, const IpxResult &r, const int8_t *rd,
 
 IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
 {
+    IPX_RAISE_PRIO(b);
     // 64 consecutive jobs per round: their reads are contiguous in HBM, so the wave copies them into LDS with coalesced loads
     // and every lane then walks its own read there (the per-lane backwards byte walk straight from HBM fetched ~6 KB per
     // read).  The ungapped test settles about half of the reads.  The others are QUEUED in LDS and the bands run on full waves of
@@ -2447,6 +2452,7 @@ IPX_KERNEL_WAVE void k_prove_overflow(IpxBatch b, int lds_cap, int chunk_blocks)
 static inline int ipx_proved_lds_bytes() { return 64 + 8 * (8 * IPX_PROVED_ROWS + IPX_PROVED_ROWS + 16); }
 IPX_KERNEL_WAVE void k_prove_overflow_diag(IpxBatch b)
 {
+    IPX_RAISE_PRIO(b);
     constexpr int BW = IPX_PROVE_BAND, HB = BW / 2, ROWS = IPX_PROVED_ROWS, GB = 8 * ROWS + ROWS + 16;
     static_assert(BW == 15, "eight lanes hold fifteen diagonals");
     const int lane = lane_id(), kl = lane & 7, g = lane >> 3;
@@ -2710,6 +2716,7 @@ IPX_DEV bool prove_plain_band(const IpxBatch &b, const IpxProveTarget &t, const 
 template <bool REV>
 IPX_KERNEL_WAVE void k_prove_plain(IpxBatch b, int chunk_blocks)
 {
+    IPX_RAISE_PRIO(b);
     const int lane = lane_id();
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
     uint32_t *qa = (uint32_t *)(IPX_LDS_BASE + 64);                // jobs waiting for the narrow band
@@ -2855,6 +2862,7 @@ IPX_DEV bool tb_ungapped(const IpxBatch &b, const IpxResult &r, int64_t i, int n
 #define IPX_TB_NCOUNTERS 12
 IPX_KERNEL void k_tb_list(IpxBatch b, uint32_t *lists, uint32_t *counters, uint32_t *esc, int all_general, int ungapped)
 {
+    IPX_RAISE_PRIO(b);
     uint64_t *coltab = (uint64_t *)IPX_LDS_BASE;                   // [read letter a] -> bytes mat[c][a], c = 0..4
     if (IPX_TID < 5) {
         uint64_t t = 0;
@@ -3140,6 +3148,7 @@ template <int BW>
 IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t *list_n, int rowcap,
                                unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n)
 {
+    IPX_RAISE_PRIO(b);
     tb_fast_body<BW, true>(b, list, list_n, rowcap, dir_scratch, next, next_n, (int)IPX_BID, (int)IPX_GDIM, (int)IPX_BID);
 }
 
@@ -3151,6 +3160,7 @@ IPX_KERNEL_WAVE void k_tb_fast(IpxBatch b, const uint32_t *list, const uint32_t 
 IPX_KERNEL_WAVE void k_tb_fast_all(IpxBatch b, const uint32_t *lists, const uint32_t *counters, int rowcap,
                                    unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n, int per, int bw_first)
 {
+    IPX_RAISE_PRIO(b);
     const int bid = (int)IPX_BID, bw = bw_first + bid / per, loc = bid % per;
     const uint32_t *list = lists + (int64_t)bw * b.n_jobs, *cnt = counters + bw;
     switch (bw) {
@@ -3201,6 +3211,7 @@ static inline int ipx_tbc_lds_bytes(int arrcap) { return 64 + 512 + 2 * IPX_TBC_
 IPX_KERNEL_WAVE void k_tb_coop(IpxBatch b, const uint32_t *list, const uint32_t *list_n, uint8_t *dir_scratch,
                                int64_t dircap, int arrcap_g, uint32_t *cig_scratch, int cigcap, int32_t *band_scratch, int arrcap_lds)
 {
+    IPX_RAISE_PRIO(b);
     const int lane = lane_id();
     unsigned char *lds = IPX_LDS_BASE;
     int8_t *matl = (int8_t *)lds;
@@ -3482,6 +3493,7 @@ template <int LG> IPX_DEV uint32_t tbd_group_umax(uint32_t x)
 template <int LG>
 IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t *list_n, uint32_t *next, uint32_t *next_n, uint32_t *coop, uint32_t *coop_n)
 {
+    IPX_RAISE_PRIO(b);
     constexpr int NG = 64 / LG, ROWS = IPX_TBD_ROWS, REFCAP = ROWS + LG, NW = (ROWS + LG) / 4, GB = ipx_tbd_group_bytes(LG);
     const int lane = lane_id(), k = lane % LG, grp = lane / LG;
     unsigned char *lds = IPX_LDS_BASE;

@@ -481,6 +481,7 @@ static int ipx_run_impl(ipx_ctx *c, bool allow_speculation)
     { int mx = 0; for (int k = 0; k < 25; ++k) if (c->mat[k] > mx) mx = c->mat[k]; b.max_match = mx; }
     b.exact_direct = ipx_perm_profile_ok(c->mat, c->routing) && !(c->routing & IPX_ROUTE_NO_EXACT_DIRECT);   // (the stepped selector-profile kernels: cheap where no cut can happen)
     b.tb_diag = !(c->routing & IPX_ROUTE_TB_NO_DIAG);
+    b.lat_prio = !(c->routing & IPX_ROUTE_NO_SETPRIO);
     b.bias = c->bias; b.flag = (uint8_t)c->flag; b.score_size = (uint8_t)c->score_size;
     b.filters = (uint16_t)c->filters; b.filterd = c->filterd;
     b.cigar_pool = c->cigar_pool.as<uint32_t>(); b.cigar_cap = c->cigar_cap;

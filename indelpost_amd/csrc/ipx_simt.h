@@ -29,6 +29,7 @@ struct uint2 { uint32_t x, y; };
 #define IPX_NOUNROLL
 #define IPX_RESTRICT
 #define IPX_KEEP_VGPR(x) ((void)0)
+#define IPX_RAISE_PRIO(b) ((void)0)
 namespace ipx_emu {
 struct LaneCtx { int tid; int bid; int gdim; int bdim; unsigned char *lds; };
 LaneCtx &cur();
@@ -166,6 +167,10 @@ IPX_DEV pk16 pkh_max3(pk16 a, pk16 b, pk16 c) { return pkh_max(pkh_max(a, b), c)
 #define IPX_RESTRICT __restrict__
 // keep a value in a vector register of its own (the compiler may not re-derive it from a lane mask)
 #define IPX_KEEP_VGPR(x) asm volatile("" : "+v"(x))
+// r04: the latency-bound kernels (proofs, planner, traceback, the stepped passes' tier launch) raise their waves' issue priority: beside
+// the other streams' wavefront kernels -- old waves whose hand-scheduled stripes never leave the vector ALU a free slot -- their dependent
+// chains otherwise advance a few instructions per turn (config 4, four streams: 2.4 to 6 times their duration alone)
+#define IPX_RAISE_PRIO(b) do { if ((b).lat_prio) __builtin_amdgcn_s_setprio(3); } while (0)
 #define IPX_TID ((int)threadIdx.x)
 #define IPX_BID ((int)blockIdx.x)
 #define IPX_GDIM ((int)gridDim.x)

@@ -94,6 +94,7 @@ enum {
     IPX_ROUTE_NO_SPECULATE = 524288,      // the latency tier launches every pass, also those the previous run found empty
     IPX_ROUTE_TEST_SKIP_ALL = 1048576 * 2, // (testing) every dynamic pass of the latency tier is predicted empty: the guard must notice and the run be repeated
     IPX_ROUTE_NO_WIDE = 262144,           // reads of 64 segments or more take the transcribed loops (k_dp_long) in the 16-bit passes too (default: one wavefront per read, k_dp_wide)
+    IPX_ROUTE_NO_SETPRIO = 4194304,       // the latency-bound kernels keep the default wave priority
     IPX_ROUTE_FORCE_LAT = 65536,          // (testing) the latency tier whatever the batch size, where its other conditions hold
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };
@@ -131,6 +132,7 @@ struct IpxBatch {
     uint8_t use_bracket;        // an upper-bound stage exists for this batch (selector-profile kernels): speed only
     uint8_t plain_first;        // the 8-bit passes of this batch take the plain-first flow (IPX_PASS_BYTE_FIRST): speed only
     int32_t max_match;          // largest matrix entry
+    int32_t lat_prio;           // the latency-bound kernels raise their waves' issue priority (s_setprio; off: IPX_ROUTE_NO_SETPRIO)
     int32_t plain_max_len;      // plain-first flow: reads up to this length take the plain kernels, longer 8-bit starters the stepped pass at once
     uint8_t exact_direct;       // what the proofs (k_prove_overflow, k_prove_plain) leave open goes to the stepped pass at once: speed only
     const uint8_t *cls_map;     // [IPX_NUM_PASSES][IPX_NUM_CLASSES] class a job of (pass, class) is LISTED under, or nullptr = its own.  The

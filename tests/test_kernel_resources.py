@@ -29,6 +29,9 @@ BUDGET = {  # kernel name prefix: (max registers, max spilled registers)
     "k_prove_overflow": (128, 0),
     "k_tb_coop": (128, 0),
     "k_tb_fast<2>": (128, 0),
+    "k_dp_wide<16, false>": (256, 0),           # r04 reads beyond 504 bp, one wavefront per read: two waves per SIMD for up to 1 024 rows ...
+    "k_dp_wide<32, false>": (256, 0),           # ... one wave, no accumulation registers, up to 2 048 ...
+    "k_dp_wide<64, false>": (512, 400),         # ... and the whole register file of a SIMD at 4 096 (what does not fit the 256 architectural registers lives in accumulation registers, not in memory)
 }
 
 
@@ -43,13 +46,16 @@ def test_register_budgets_of_the_hot_kernels():
         for o in objs:
             rows += kernel_regs.kernels_of(o, tmp)
     names = subprocess.run(["c++filt"], input="\n".join(r.get(".name", "?") for r in rows), capture_output=True, text=True).stdout.split("\n")
-    seen = {}
+    seen, private = {}, {}
     for r, n in zip(rows, names):
         n = n.replace("void ", "").split("(")[0]
         seen[n] = (int(r.get(".vgpr_count", 0)), int(r.get(".vgpr_spill_count", 0)))
+        private[n] = int(r.get(".private_segment_fixed_size", 0))
     for k, (vmax, smax) in BUDGET.items():
         assert k in seen, "kernel %s not found in the built objects" % k
         v, sp = seen[k]
+        if k.startswith("k_dp_wide"):
+            assert private.get(k, 0) == 0, "%s keeps %d bytes per lane in private memory" % (k, private[k])
         assert v <= vmax and sp <= smax, "%s: %d registers, %d spilled (budget %d / %d)" % (k, v, sp, vmax, smax)
 
 
