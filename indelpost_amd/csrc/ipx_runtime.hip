@@ -393,6 +393,19 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     int w1 = c->num_cu * 16;                                  // one job per block in k_tb_coop (latency-bound: many blocks)
     const size_t lim1 = 1024ull << 20;
     while (w1 > 1 && ipx_tbc_bytes_per_block(s1) * (size_t)w1 > lim1) w1 /= 2;
+    if (w1 < 64) {
+        // reads of kilobases against windows of tens of kilobases: a block's region (direction bytes for the widest band the rectangle allows)
+        // is tens of megabytes and a gigabyte holds a handful -- 2 kb against 20 kb: 8 jobs at a time, 111 ms of traceback for 256 reads whose
+        // DP passes take 28 (r04, k_dp_wide).  The card has 288 GB: up to 64 regions, within 16 GB and a sixteenth of what is free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            size_t cap = free_b / 16;
+            if (cap > (16ull << 30)) cap = 16ull << 30;
+            int w = 64;
+            while (w > w1 && ipx_tbc_bytes_per_block(s1) * (size_t)w > cap) w /= 2;
+            if (w > w1) w1 = w;
+        }
+    }
     c->ws.tb1_waves = w1;
     if (c->tb1.ensure(ipx_tbc_bytes_per_block(s1) * (size_t)w1)) return IPX_ERR_NO_DEVICE;
     memset(&c->ws.tb1, 0, sizeof c->ws.tb1);
