@@ -158,10 +158,12 @@ def lib():
 def load(path):
     """a shared object with the library's C ABI (the product library, or a test variant of it), signatures declared"""
     # HIP gives a process four hardware queues by default and multiplexes its streams onto them; two aligners in rotation (eight streams:
-    # while one batch computes, the next one's slices copy in) then wait for each other inside a shared queue.  Eight queues, unless the
-    # caller has said otherwise -- read by the HIP runtime when it initialises, i.e. at the first call into the library (r04: the many-loci
-    # stream 45.7 -> 54.1 M aln/s; batches resident in HBM within +-1 %)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # while one batch computes, the next one's slices copy in) then wait for each other inside a shared queue.  Ten queues -- the eight
+    # streams and what the runtime uses itself: with exactly eight, every other list of the many-loci stream still took 26 ms instead of
+    # 14 -- unless the caller has said otherwise; read by the HIP runtime when it initialises, i.e. at the first call into the library
+    # (r04, many-loci stream through align_loci_stream: 4 queues 45.7, 8 queues 60-65, 10 queues 73-78 M aln/s; batches resident in HBM
+    # within +-1 % at 4, 8, 10 or 16)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
     L = C.CDLL(path)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
     L.ipx_device_count.restype = C.c_int

@@ -489,6 +489,39 @@ class GpuAligner:
         return float(self._L.ipx_last_run_ms(self._ctx))
 
 
+class LociStaging:
+    """Page-locked, reused INPUT arrays for concatenated job tables: call it with the sizes JobTable.concat asks for and get the eight
+    arrays to fill (reads, read_off, refs, ref_off, ref_id, gap_open, gap_ext, mask_len or None), cut to size.  The buffers grow to
+    the largest batch seen (+25 %) and are registered with the HIP runtime once (hipHostRegister through ipx_pin_host), so that the copies
+    in are asynchronous.  What was handed out stays valid until the next call.  Plain arrays on back-ends without the capability."""
+
+    def __init__(self, library):
+        self._L = library if library is not None and hasattr(library, "ipx_pin_host") else None
+        self._st, self._pinned = None, []
+
+    def __call__(self, rb, fb, nj, nr, with_mask):
+        if self._L is None:
+            return (np.empty(rb, np.int8), np.empty(nj + 1, np.int64), np.empty(fb, np.int8), np.empty(nr + 1, np.int64), np.empty(nj, np.int32),
+                    np.empty(nj, np.uint8), np.empty(nj, np.uint8), np.empty(nj, np.int32) if with_mask else None)
+        st, need = self._st, (rb, fb, nj + 1, nr + 1)
+        if st is None or any(n > c for n, c in zip(need, st["cap"])) or (with_mask and st["mask"] is None):
+            self.close()
+            cap = tuple(int(n * 1.25) + 1024 for n in need)
+            st = self._st = {"cap": cap, "reads": np.empty(cap[0], np.int8), "read_off": np.empty(cap[2], np.int64), "refs": np.empty(cap[1], np.int8),
+                             "ref_off": np.empty(cap[3], np.int64), "ref_id": np.empty(cap[2], np.int32), "go": np.empty(cap[2], np.uint8),
+                             "ge": np.empty(cap[2], np.uint8), "mask": np.empty(cap[2], np.int32) if with_mask else None}
+            for a in (st["reads"], st["read_off"], st["refs"], st["ref_off"], st["ref_id"], st["go"], st["ge"], st["mask"]):
+                if a is not None and a.nbytes and self._L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
+                    self._pinned.append(a)
+        return (st["reads"][:rb], st["read_off"][:nj + 1], st["refs"][:fb], st["ref_off"][:nr + 1], st["ref_id"][:nj], st["go"][:nj], st["ge"][:nj],
+                st["mask"][:nj] if with_mask else None)
+
+    def close(self):
+        for a in self._pinned:
+            self._L.ipx_unpin_host(C.c_void_p(a.ctypes.data))
+        self._st, self._pinned = None, []
+
+
 class MultiStreamAligner:
     """Several HIP streams on ONE GPU: the job table is cut into `streams` contiguous slices, each
     slice runs the whole pipeline on its own stream (its own ipx_ctx and workspace).  The slices are
@@ -505,6 +538,8 @@ class MultiStreamAligner:
         self._pinned = []            # host arrays page-locked by pin_host (kept alive here)
         self._out = None             # pinned (records, cigar pool) pairs, used in alternation by collect(): see pin_host
         self._out_turn = 0
+        self._staging = None         # page-locked input staging of loci_staging (a LociStaging)
+        self._out_pinned, self._out_loci = [], False     # the output pairs ensure_outputs made
 
     def close(self):
         self.unpin()
@@ -543,7 +578,7 @@ class MultiStreamAligner:
         for a in (jobs.reads, jobs.read_off, jobs.refs, jobs.ref_off, jobs.ref_id, jobs.gap_open, jobs.gap_ext, jobs.mask_len) + out[0] + out[1]:
             if a is not None and a.nbytes and L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
                 self._pinned.append(a)
-        self._out = out
+        self._out, self._out_loci = out, False
         for p in self.parts:
             p.set_async_io(True)
         return True
@@ -553,36 +588,39 @@ class MultiStreamAligner:
         straight into them, the slices' copies in and out are asynchronous, and nothing is allocated or registered per batch once the
         buffers have grown to the largest batch seen (+25 %).  Returns the eight input arrays cut to the sizes asked for.  Same
         lifetime rule for results as pin_host."""
+        if self._staging is None:
+            self._staging = LociStaging(getattr(self.parts[0], "_L", None))
+        arrays = self._staging(rb, fb, nj, nr, with_mask)
+        self.ensure_outputs(nj, cigar_ops_per_job)
+        return arrays
+
+    def ensure_outputs(self, nj, cigar_ops_per_job=16):
+        """two page-locked (records, CIGAR pool) pairs for batches of up to nj jobs, used in turn by collect(); the contexts switch to
+        asynchronous transfers.  Nothing happens once they are large enough (they grow by a quarter beyond what is asked for)."""
         L = getattr(self.parts[0], "_L", None)
         if L is None or not hasattr(L, "ipx_pin_host"):
-            return (np.empty(rb, np.int8), np.empty(nj + 1, np.int64), np.empty(fb, np.int8), np.empty(nr + 1, np.int64), np.empty(nj, np.int32),
-                    np.empty(nj, np.uint8), np.empty(nj, np.uint8), np.empty(nj, np.int32) if with_mask else None)
-        st = getattr(self, "_loci", None)
-        need = (rb, fb, nj + 1, nr + 1)
-        if st is None or any(n > c for n, c in zip(need, st["cap"])) or (with_mask and st["mask"] is None):
-            self.unpin()
-            cap = tuple(int(n * 1.25) + 1024 for n in need)
-            st = self._loci = {"cap": cap, "reads": np.empty(cap[0], np.int8), "read_off": np.empty(cap[2], np.int64), "refs": np.empty(cap[1], np.int8),
-                               "ref_off": np.empty(cap[3], np.int64), "ref_id": np.empty(cap[2], np.int32), "go": np.empty(cap[2], np.uint8),
-                               "ge": np.empty(cap[2], np.uint8), "mask": np.empty(cap[2], np.int32) if with_mask else None}
-            k = len(self.parts)
-            out = [(np.empty(cap[2], RESULT_DTYPE), np.empty(cap[2] * cigar_ops_per_job + 1024 * k, np.uint32)) for _ in (0, 1)]
-            for a in (st["reads"], st["read_off"], st["refs"], st["ref_off"], st["ref_id"], st["go"], st["ge"], st["mask"]) + out[0] + out[1]:
-                if a is not None and a.nbytes and L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
-                    self._pinned.append(a)
-            self._out = out
-            for p in self.parts:
-                p.set_async_io(True)
-        return (st["reads"][:rb], st["read_off"][:nj + 1], st["refs"][:fb], st["ref_off"][:nr + 1], st["ref_id"][:nj], st["go"][:nj], st["ge"][:nj],
-                st["mask"][:nj] if with_mask else None)
+            return False
+        if self._out is not None and self._out_loci and len(self._out[0][0]) >= nj:
+            return True
+        for a in self._out_pinned:
+            L.ipx_unpin_host(C.c_void_p(a.ctypes.data))
+        cap, k = int(nj * 1.25) + 1024, len(self.parts)
+        out = [(np.empty(cap, RESULT_DTYPE), np.empty(cap * cigar_ops_per_job + 1024 * k, np.uint32)) for _ in (0, 1)]
+        self._out_pinned = [a for a in out[0] + out[1] if L.ipx_pin_host(C.c_void_p(a.ctypes.data), a.nbytes) == 0]
+        self._out, self._out_loci = out, True
+        for p in self.parts:
+            p.set_async_io(True)
+        return True
 
     def unpin(self):
-        self._loci = None
+        if self._staging is not None:
+            self._staging.close()
+            self._staging = None
         L = getattr(self.parts[0], "_L", None) if self.parts else None
-        for a in self._pinned:
+        for a in self._pinned + self._out_pinned:
             if L is not None:
                 L.ipx_unpin_host(C.c_void_p(a.ctypes.data))
-        self._pinned, self._out = [], None
+        self._pinned, self._out_pinned, self._out, self._out_loci = [], [], None, False
         for p in self.parts:
             if hasattr(p, "set_async_io") and getattr(p, "_ctx", None):
                 p.set_async_io(False)
@@ -799,3 +837,68 @@ def align_loci(tables, match_score=2, mismatch_penalty=2, device=0, aligner=None
         aligner.set_scoring(matrix=dna_score_matrix(match_score, mismatch_penalty), flag=1, score_size=2)
     table = JobTable.concat(tables, staging=getattr(aligner, "loci_staging", None))
     return aligner.align(table).split(table.table_jobs if len(tables) else [])
+
+
+def align_loci_stream(lists, match_score=2, mismatch_penalty=2, device=0, depth=2, streams=4, aligner_cls=None):
+    """A STREAM of locus lists (a caller working through a VCF: one list of per-locus JobTables per chunk of rows): a generator that yields,
+    for every list of `lists` and in order, what align_loci returns for it.  Three stages overlap: a host thread concatenates list k+1 into
+    one of depth + 1 page-locked staging sets (JobTable.concat -> ipx_concat_tables: the library's copy, no GIL); the caller's thread
+    enqueues list k on aligner k % depth (copies in, pipeline) and then collects list k-1 (copies out, split), so the GPU always has the
+    next batch queued.  Two aligners of four streams are the eight hardware queues the loader asks the HIP runtime for (_lib.load); a
+    third aligner -- twelve streams -- runs into queue sharing again (r04: 21.7 ms per 1.2 M-job list against 16.5).
+    LIFETIME: the BatchResults yielded are views of the aligners' page-locked output buffers; they stay valid until 2 * depth - 1 more
+    lists have been yielded (BatchResult.copy() detaches them)."""
+    import queue
+    import threading
+    depth = max(1, depth)
+    ring = [MultiStreamAligner(device, match_score, mismatch_penalty, streams=streams, aligner_cls=aligner_cls) for _ in range(depth)]
+    stages = [LociStaging(getattr(ring[0].parts[0], "_L", None)) for _ in range(depth + 1)]
+    free = [threading.Semaphore(1) for _ in stages]                # a staging set may be overwritten: the list made in it is collected
+    ready = queue.Queue(maxsize=len(stages))
+    stop = threading.Event()
+
+    def feeder():
+        try:
+            for k, tables in enumerate(lists):
+                s = k % len(stages)
+                while not free[s].acquire(timeout=0.1):
+                    if stop.is_set():
+                        return
+                tables = tables if isinstance(tables, (list, tuple)) else list(tables)
+                ready.put((k, JobTable.concat(tables, staging=stages[s]) if tables else None))
+            ready.put((None, None))
+        except BaseException as e:                                 # (the consumer re-raises it)
+            ready.put((None, e))
+
+    th = threading.Thread(target=feeder, daemon=True)
+    th.start()
+
+    def finish(pending):
+        k, table = pending
+        out = ring[k % depth].collect().split(table.table_jobs) if table is not None else []
+        free[k % len(stages)].release()
+        return out
+    try:
+        pending = None                                             # (list number, table) submitted, not collected
+        while True:
+            k, table = ready.get()
+            if k is None:
+                if isinstance(table, BaseException):
+                    raise table
+                break
+            if table is not None:
+                a = ring[k % depth]
+                a.ensure_outputs(table.n_jobs)
+                a.submit(table)
+            if pending is not None:
+                yield finish(pending)
+            pending = (k, table)
+        if pending is not None:
+            yield finish(pending)
+    finally:
+        stop.set()
+        th.join(timeout=5)
+        for r in ring:
+            r.close()
+        for st in stages:
+            st.close()

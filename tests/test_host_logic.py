@@ -263,6 +263,48 @@ def test_concat_and_split_round_trip(emu):
             assert all(p.as_dict(i) == alone.as_dict(i) for i in range(t.n_jobs))
 
 
+def test_stream_of_locus_lists(emu):
+    """align_loci_stream: a generator over lists of per-locus tables -- concatenation on a host thread, submit / collect on the caller's,
+    a ring of three aligners -- yields, list by list and in order, what align_loci gives for each; empty lists and empty tables included;
+    an exception in the producer surfaces in the consumer; abandoning the generator closes the aligners"""
+    from indelpost_amd.batch import align_loci, align_loci_stream
+    rng = np.random.default_rng(77)
+
+    def locus():
+        wins = [rng.integers(0, 4, int(rng.integers(60, 120))).astype(np.int8) for _ in range(int(rng.integers(1, 3)))]
+        reads, rid = [], []
+        for i in range(int(rng.integers(0, 5))):
+            w = int(rng.integers(0, len(wins)))
+            st = int(rng.integers(0, 20))
+            r = wins[w][st:st + 40].copy()
+            r[int(rng.integers(0, 40))] ^= 2
+            reads.append(r); rid.append(w)
+        return JobTable.from_sequences(reads, wins, np.array(rid, np.int32), 3, 1, encoded=True)
+    lists = [[locus() for _ in range(int(rng.integers(1, 6)))] for _ in range(7)]
+    lists.insert(3, [])
+    one = emu(0, 3, 2)
+    n = 0
+    for tables, parts in zip(lists, align_loci_stream(iter(lists), 3, 2, streams=2, aligner_cls=emu)):
+        want = align_loci(tables, aligner=one) if tables else []
+        assert [len(p) for p in parts] == [t.n_jobs for t in tables]
+        for p, q in zip(parts, want):
+            assert all(p.as_dict(i) == q.as_dict(i) for i in range(len(q)))
+        n += 1
+    assert n == len(lists)
+
+    def broken():
+        yield lists[0]
+        raise ValueError("no more rows")
+    gen = align_loci_stream(broken(), 3, 2, streams=2, aligner_cls=emu)
+    import pytest
+    with pytest.raises(ValueError):
+        for _ in gen:
+            pass
+    gen = align_loci_stream(iter(lists), 3, 2, streams=2, aligner_cls=emu)
+    next(gen)
+    gen.close()                                                      # (the feeder thread stops, the ring is closed)
+
+
 def test_pinned_output_bookkeeping_of_the_multi_stream_aligner(emu):
     """collect() with page-locked output buffers (here: plain arrays handed in as if pin_host had made them): every slice is copied
     into its range of ONE record array and its region of ONE cigar pool, cigar offsets rebased; two output pairs are used in turn, so

@@ -13,4 +13,4 @@ if len(sys.argv) > 2 and sys.argv[2] == "0":
     batch.MultiStreamAligner.__init__ = init
 bench_modes.run_many_loci(ip, (3, 2), 0, 4, 2)
 rec = bench_modes.run_many_loci(ip, (3, 2), 0, 4, steps)
-print(json.dumps({k: rec[k] for k in ("value", "ms_per_step", "host_ms_per_step", "one_list_at_a_time")}))
+print(json.dumps({k: rec[k] for k in ("value", "ms_per_step", "form", "align_loci_stream", "two_aligners_one_thread", "host_ms_per_step", "one_list_at_a_time")}))
