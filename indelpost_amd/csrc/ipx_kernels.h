@@ -3161,6 +3161,32 @@ IPX_KERNEL_WAVE void k_tb_fast_all(IpxBatch b, const uint32_t *lists, const uint
                                    unsigned char *dir_scratch, uint32_t *next, uint32_t *next_n, int per, int bw_first)
 {
     IPX_RAISE_PRIO(b);
+    if (per == 0) {
+        // r04, big batches: the seven widths in ONE launch, the blocks shared out by the lists' lengths (read here: k_tb_list has filled
+        // them) -- virtual block v serves the v-th chunk of 64 jobs of the concatenated lists.  Four launches in a row (1, 2, 3, 4..7) were four
+        // ramps of a thousand waves each through wave slots the other streams' wavefront kernels keep full (config 4, four streams: 2.75 ms
+        // of a slice's 16.6 ms step).  A band that has to double goes to the anti-diagonal tiers (no later launch of this kernel to take it).
+        uint32_t first[IPX_TBF_MAXBW + 1];
+        first[0] = 0;
+        for (int w = 0; w < IPX_TBF_MAXBW; ++w) first[w + 1] = first[w] + (counters[w] + 63u) / 64u;
+        for (uint32_t v = (uint32_t)IPX_BID; v < first[IPX_TBF_MAXBW]; v += (uint32_t)IPX_GDIM) {
+            int w = 0;
+            while (v >= first[w + 1]) ++w;
+            const int loc = (int)(v - first[w]), cnt_w = (int)(first[w + 1] - first[w]);
+            const uint32_t *list = lists + (int64_t)w * b.n_jobs, *cnt = counters + w;
+            IPX_SYNC();                                               // (the previous chunk's lanes are done with the score table and the CIGAR buffer)
+            switch (w) {
+            case 0: tb_fast_body<1, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            case 1: tb_fast_body<2, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            case 2: tb_fast_body<3, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            case 3: tb_fast_body<4, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            case 4: tb_fast_body<5, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            case 5: tb_fast_body<6, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            default: tb_fast_body<7, false>(b, list, cnt, rowcap, dir_scratch, next, next_n, loc, cnt_w, (int)IPX_BID); break;
+            }
+        }
+        return;
+    }
     const int bid = (int)IPX_BID, bw = bw_first + bid / per, loc = bid % per;
     const uint32_t *list = lists + (int64_t)bw * b.n_jobs, *cnt = counters + bw;
     switch (bw) {

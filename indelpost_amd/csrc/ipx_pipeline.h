@@ -12,7 +12,6 @@
 // batch (ipx_build_static_plans); every other pass is counted by the kernels that send jobs into it and needs one
 // scatter launch (k_plan_scatter) on the stream.
 #pragma once
-#include <stdlib.h>
 #include <string.h>
 #include "ipx_kernels.h"
 
@@ -528,6 +527,11 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
                 const int per = per_want < per_have ? per_want : per_have;
                 be.launch(IPX_KEY(IPX_K_TRACEBACK, 9), k_tb_fast_all, 7 * per, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
                           (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, per, 0);
+            } else if (!(routing & (IPX_ROUTE_TB_NO_FUSE | IPX_ROUTE_TB_PER_WIDTH)) && b.tb_diag) {
+                // r04, big batches: one launch for all seven widths, its blocks shared out by the lists' lengths on the device
+                // (the grid: a block per chunk where the scratch allows -- 512 to 2 048 blocks walking several chunks each were no faster)
+                be.launch(IPX_KEY(IPX_K_TRACEBACK, 9), k_tb_fast_all, ws.tbf_waves, 64, ipx_tbf_lds_bytes(), b, (const uint32_t *)ws.tb_list,
+                          (const uint32_t *)ws.tb_list_n, rowcap, ws.tbf_scratch, ws.tb_esc, ws.tb_esc_n, 0, 0);
             } else {
                 // widths 1..3 (nearly every job): their own launches.  (Direction words in LDS instead of the global scratch were
                 // measured in r02 and dropped: 46 KB per one-wave block leaves 3 waves per CU, and the lane-per-job walk needs

@@ -78,7 +78,10 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True, fast_gaps_only=False):
                                            ((3, 2), (R.ROUTE_FORCE_LAT, "fast_gaps")), ((1, 1), (R.ROUTE_FORCE_LAT, "fast_gaps")), ((2, 2), (R.ROUTE_FORCE_LAT, "fast_gaps")),
                                            ((5, 4), (R.ROUTE_FORCE_LAT, "fast_gaps")), ((3, 2), ("small", "fast_gaps")), ((3, 2), ("small", "fast_gaps", R.ROUTE_NO_LAT)),
                                            ((3, 2), ("tiny", "fast_gaps")), ((1, 1), ("tiny",)), ((3, 2), (R.ROUTE_FORCE_LAT, R.ROUTE_NO_LAT_PROOF, "fast_gaps")),
-                                           ((2, 2), ("tiny", "fast_gaps"))])
+                                           ((2, 2), ("tiny", "fast_gaps")),
+                                           # r04 (second half): the lane-per-job tracebacks one launch per band width again (default: one launch, blocks shared out
+                                           # on the device), the latency-bound kernels at the default wave priority
+                                           ((3, 2), (R.ROUTE_TB_PER_WIDTH,)), ((1, 3), (R.ROUTE_TB_PER_WIDTH, R.ROUTE_NO_SETPRIO, "fast_gaps")), ((2, 2), (R.ROUTE_NO_SETPRIO,))])
 def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd):
     from oracle.oracle import cpu_batch_results, fnv1a_ops
     fast = "fast_gaps" in knobs
