@@ -663,10 +663,12 @@ static inline void ipx_merge_classes(const uint32_t *n, int top, bool merge, uin
     }
 }
 // reverse pass: launches for c and c-1 of every kept forward class, every other prefix class listed under the next launch
-static inline void ipx_reverse_classes(const uint8_t *kept_a, const uint8_t *kept_b, int top, uint8_t *map, uint8_t *set, const uint8_t *extra)
+// (r04, second half: `below` = false lists class c-1 under c as well -- a prefix eight rows shorter costs the longer kernel 1/c more work and the
+//  stream one launch, with its ramp and its tail, less per forward class)
+static inline void ipx_reverse_classes(const uint8_t *kept_a, const uint8_t *kept_b, int top, uint8_t *map, uint8_t *set, const uint8_t *extra, bool below = true)
 {
     for (int c = 1; c <= top; ++c)
-        if (kept_a[c] || (kept_b && kept_b[c]) || (extra && extra[c])) { set[c] = 1; if (c > 1 && !(extra && extra[c] && !kept_a[c] && !(kept_b && kept_b[c]))) set[c - 1] = 1; }
+        if (kept_a[c] || (kept_b && kept_b[c]) || (extra && extra[c])) { set[c] = 1; if (below && c > 1 && !(extra && extra[c] && !kept_a[c] && !(kept_b && kept_b[c]))) set[c - 1] = 1; }
     int target = -1;
     for (int c = top; c >= 0; --c) {
         if (set[c]) target = c;
@@ -730,7 +732,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
         uint8_t reach[IPX_NUM_CLASSES];
         memset(reach, 0, sizeof reach);
         reach[all16 < fmax16 ? (all16 > 0 ? all16 : 1) : fmax16] = 1;
-        ipx_reverse_classes(d.set[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FWD], fmax16, d.cls_map[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], reach);
+        ipx_reverse_classes(d.set[IPX_PASS_WORD_FIRST], d.set[IPX_PASS_WORD_FWD], fmax16, d.cls_map[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], reach, (routing & IPX_ROUTE_REV_BELOW) != 0);
     }
     // 8-bit passes as the plain recurrence
     const bool plain_ok = b.score_size != 1 && top8 >= 1;
@@ -743,7 +745,7 @@ static inline void ipx_plan_classes(IpxDims &d, const IpxBatch &b, int routing)
         d.plain_first = 1;
         d.plain_max_len = 16 * fmax8;
         ipx_merge_classes(n8low, top8, merge, d.cls_map[IPX_PASS_BYTE_FIRST], d.set[IPX_PASS_BYTE_FIRST]);
-        if (merge) ipx_reverse_classes(d.set[IPX_PASS_BYTE_FIRST], nullptr, top8, d.cls_map[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], nullptr);
+        if (merge) ipx_reverse_classes(d.set[IPX_PASS_BYTE_FIRST], nullptr, top8, d.cls_map[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], nullptr, (routing & IPX_ROUTE_REV_BELOW) != 0);
         else { for (int c = 1; c <= top8; ++c) d.set[IPX_PASS_BYTE_REV_PLAIN][c] = 1; d.cls_map[IPX_PASS_BYTE_REV_PLAIN][0] = 1; }
     } else if (plain_ok && b.use_bracket && top8 == all8) {
         // bracket flow: the upper-bound stage as a wavefront (r02) when every 8-bit class of the batch is within its reach, its rare
