@@ -136,7 +136,13 @@ int ipx_set_params(ipx_ctx *c, const int8_t *mat, int flag, int filters, int fil
  * 512 one launch per read-length class (no rare class listed under the next populated one)
  *1024 one launch per class instead of one per occupancy tier (wavefront kernels and the stepped 8-bit passes)
  *2048 what a proof leaves open takes the lower-bound stage before the stepped pass
- *4096 small batches too take the lane-per-job traceback kernels      8192 every CIGAR through banded_sw's DP (no ungapped shortcut) */
+ *4096 small batches too take the lane-per-job traceback kernels      8192 every CIGAR through banded_sw's DP (no ungapped shortcut)
+ *16384 no anti-diagonal traceback tiers     32768 no latency tier for small batches     65536 (testing) latency tier forced
+ *131072 latency tier keeps the lane-per-read overflow proof     524288 latency tier launches every pass (no speculation on empty ones)
+ *262144 reads of 505 bp and more take the transcribed loops (k_dp_long) in the 16-bit passes too, not one wavefront per read (k_dp_wide)
+ *4194304 the latency-bound kernels keep the default wave priority     8388608 big batches: one lane-per-job traceback launch per band width
+ *16777216 the reverse passes launch class c - 1 beside every forward class c
+ * (csrc/ipx_types.h IPX_ROUTE_* is the authoritative list) */
 int ipx_set_routing(ipx_ctx *c, int flags);
 
 /* Stage a job table in HBM.  reads/refs: concatenated int8 codes (0..4); read_off: n_jobs+1,
