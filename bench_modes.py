@@ -16,7 +16,8 @@ def run_end_to_end(ip, jobs, scoring, dev, streams, steps, depth=None):
     """A stream of job tables through ONE GPU, host memory to host memory.  `depth` aligners take the batches in turn: while
     one computes, another's results are downloaded and a third's next batch is cut, copied in and launched, so the GPU does
     not wait for the host or the PCIe link (each aligner: `streams` contexts, its own device buffers)."""
-    depth = depth or int(os.environ.get("IPX_E2E_DEPTH", "3"))
+    # (r04: two aligners -- eight streams, within the ten hardware queues the loader asks for: 78 M aln/s; three: 71; r03, four queues, three aligners: 62.5)
+    depth = depth or int(os.environ.get("IPX_E2E_DEPTH", "2"))
     ring = [ip.MultiStreamAligner(dev, scoring[0], scoring[1], streams=streams) for _ in range(depth)]
     try:
         pinned = all([g.pin_host(jobs) for g in ring])           # input arrays shared, one pinned output pair per aligner
