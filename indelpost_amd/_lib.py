@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 SRC = os.path.join(CSRC, "ipx_runtime.hip")
 # the library is several translation units (compiled in parallel): the runtime + every other kernel, and twenty
 # units holding the explicit instantiations of the striped-DP kernel families (csrc/ipx_kernels.h, end of file)
-UNITS = [SRC] + [os.path.join(CSRC, "ipx_dp_%s.hip" % u) for u in "abcdefghijklmnopqvwxy"]
+UNITS = [SRC] + [os.path.join(CSRC, "ipx_dp_%s.hip" % u) for u in "abcdefghijklmnopqvwxyz"]
 HEADERS = [os.path.join(CSRC, h) for h in ("ipx_simt.h", "ipx_types.h", "ipx_kernels.h", "ipx_pipeline.h")] + [
     os.path.join(os.path.dirname(PKG_DIR), "include", "indelpost_hip.h")]
 BUILD_DIR = os.path.join(CSRC, "build")

@@ -20,7 +20,7 @@ _OPS = "MIDNSHP=X"
 ROUTE_NO_WORD_FIRST, ROUTE_NO_PERM_PROFILE, ROUTE_NO_BRACKET, ROUTE_TB_NO_FUSE, ROUTE_NO_MC_LDS, ROUTE_NO_F16, ROUTE_NO_SKEW, ROUTE_NO_VL2 = 1, 2, 4, 8, 16, 32, 64, 128
 ROUTE_NO_PLAIN_FIRST, ROUTE_NO_CLASS_MERGE, ROUTE_NO_TIERS, ROUTE_NO_EXACT_DIRECT, ROUTE_TB_NO_WAVE_PER_JOB = 256, 512, 1024, 2048, 4096
 ROUTE_TB_NO_UNGAPPED, ROUTE_TB_NO_DIAG, ROUTE_NO_LAT, ROUTE_FORCE_LAT, ROUTE_NO_LAT_PROOF, ROUTE_NO_SPECULATE, ROUTE_TEST_SKIP_ALL = 8192, 16384, 32768, 65536, 131072, 524288, 2097152
-ROUTE_NO_WIDE, ROUTE_NO_SETPRIO, ROUTE_TB_PER_WIDTH, ROUTE_REV_BELOW = 262144, 4194304, 8388608, 16777216
+ROUTE_NO_WIDE, ROUTE_NO_SETPRIO, ROUTE_TB_PER_WIDTH, ROUTE_REV_BELOW, ROUTE_NO_BAND_REV, ROUTE_FORCE_BAND_REV = 262144, 4194304, 8388608, 16777216, 33554432, 67108864
 
 # DNA_BASE_LUT of the reference (sswpy.pyx:16-25): A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, else 4.
 # Bytes >= 128 index the reference's table out of bounds (undefined); they map to N here.

@@ -1833,6 +1833,247 @@ IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBa
 //  r03 profile showed as WRITE_SIZE -- and with the launches sized from the previous run's tile counts the per-class launches are as fast:
 //  config 4 55.8 with the tiers, 56.3 without; config 5 72.7 / 73.5.)
 // ------------------------------------------------------------------------------------------------
+// k_dp_band_rev<S> (r04): the 16-bit REVERSE pass as a band, one LANE per pair of reads.
+//
+// The reverse pass (ssw.c:875-886) exists to find where score1 is reached walking back from (read_end1, ref_end1): its outputs are the
+// first column (in its own, reversed order) whose maximum equals score1 and the smallest row holding it there.  With i / j counting rows /
+// columns from the end cell, a local alignment that starts there, covers at most `rows` read bases and drifts d diagonals away from i = j
+// contains gaps of d letters at least and scores at most max(mat) * rows - (gap_open + (d - 1) * gap_ext).  So with
+//     budget = max(mat) * rows - score1,     d_max = budget < gap_open ? 0 : (budget - gap_open) / gap_ext + 1        (gap_ext >= 1)
+// no cell with |i - j| > d_max holds score1, and no optimal path to a cell that does leaves that band (each of its prefixes is under the
+// same budget).  A recurrence restricted to |i - j| <= D >= d_max (everything outside reads 0) is cell by cell <= the full one and equal
+// along every optimal path: its column maxima reach score1 in the same column, in the same rows -- the same two outputs.  (score1 IS the
+// maximum of the full reverse matrix: the forward optimum lies inside the prefix rectangle.  Needs what k_dp_skew needs: gap_open >
+// gap_ext, scores exact in halves.)  Jobs whose budget asks for more than D = S + 1 (ipx_band_d) keep the full wavefront kernel (k_rev_split makes the
+// two lists).
+// Layout: lanes run in lockstep, so a band pays only where a lane walks its OWN column window.  A lane holds TWO reads (the halves of its
+// packed registers) and takes their rows in eight blocks of S, one after the other: block q = rows qS .. qS+S-1 over the columns
+// qS - D .. qS + S - 1 + D (+ what rounds the count up to four), with the striped recurrence of k_dp_skew (dp_stripe_f16: F runs down the
+// block's rows in registers).  What block q + 1 needs of block q -- H and F of its last row, one value each per column of the overlap --
+// waits in a ring in LDS ([column][lane]: two 8-byte accesses per step, never a bank conflict); no lane talks to another, there is no
+// wavefront skew and no lead-in.  8 x (S + 2 D + 1) steps per 128 reads instead of (columns + 7) per 16: at S = 19, D = 20 a reverse pass
+// is ~770 vector instructions per alignment instead of 2 149.  Window letters: two aligned dwords per half and group of four columns,
+// one group ahead, cut to the four letters with v_alignbyte_b32; columns outside the window get the letter that scores -2048.
+// Dynamic LDS: 128 B score table | ring of (WW - S + 1) x 64 lanes x 8 B
+// ------------------------------------------------------------------------------------------------
+// half-width of the band of class S: errors, and with them the budget, grow with the read's length (2b, 150 bp, D = 20: 72 % of the jobs eligible)
+IPX_HD constexpr int ipx_band_d(int S) { return S + 1; }
+IPX_HD constexpr int ipx_band_steps(int S) { return (S + 2 * ipx_band_d(S) + 1 + 3) & ~3; }
+static inline int ipx_band_lds_bytes(int S) { return 128 + (ipx_band_steps(S) - S + 1) * 64 * 8; }
+IPX_DEV bool band_rev_ok(const IpxBatch &b, const IpxResult &r, int gO, int gE, int D)
+{
+    const int rows = r.read_end1 + 1;
+    if (gE < 1 || gO <= gE || rows < 1 || r.score1 == 0 || r.ref_end1 < 0) return false;
+    const int budget = b.max_match * rows - (int)r.score1;
+    const int dmax = budget < gO ? 0 : (budget - gO) / gE + 1;
+    return dmax <= D;
+}
+#if IPX_AUX_KERNELS
+// the jobs of class `cls` of the reverse pass's list, sorted into those the band serves (listA) and the others (listB); cnt[0..1]: their numbers
+IPX_KERNEL_WAVE void k_rev_split(IpxBatch b, IpxPlan p, int cls, uint32_t *listA, uint32_t *listB, uint32_t *cnt)
+{
+    IPX_RAISE_PRIO(b);
+    constexpr int R = 8;                                            // jobs per lane and round of the wave: ONE pair of atomics per 512 jobs
+    const int lane = lane_id();
+    const uint32_t lo = p.cls_off[cls], n = p.cls_off[cls + 1] - lo;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t base = (uint32_t)IPX_BID * (64u * R); base < n; base += (uint32_t)IPX_GDIM * (64u * R)) {      // (uniform)
+        uint32_t job[R], pa[R], pb[R];
+        bool a[R], in[R];
+        uint32_t na = 0, nb = 0;
+        IPX_UNROLL
+        for (int k = 0; k < R; ++k) {
+            const uint32_t at = base + (uint32_t)(k * 64 + lane);
+            in[k] = at < n; a[k] = false; job[k] = 0;
+            if (in[k]) {
+                job[k] = p.perm[lo + at];
+                a[k] = band_rev_ok(b, b.res[job[k]], b.gap_open[job[k]], b.gap_ext[job[k]], ipx_band_d(cls));
+            }
+            const uint64_t ma = xl_ballot(in[k] && a[k]), mb = xl_ballot(in[k] && !a[k]);
+            pa[k] = na + (uint32_t)__builtin_popcountll(ma & below); pb[k] = nb + (uint32_t)__builtin_popcountll(mb & below);
+            na += (uint32_t)__builtin_popcountll(ma); nb += (uint32_t)__builtin_popcountll(mb);
+        }
+        uint32_t ba = 0, bb = 0;
+        if (lane == 0) {
+            if (na) ba = atomic_add_u32(&cnt[0], na);
+            if (nb) bb = atomic_add_u32(&cnt[1], nb);
+        }
+        ba = xl_first(ba); bb = xl_first(bb);
+        IPX_UNROLL
+        for (int k = 0; k < R; ++k) {
+            if (in[k] && a[k]) listA[ba + pa[k]] = job[k];
+            if (in[k] && !a[k]) listB[bb + pb[k]] = job[k];
+        }
+    }
+}
+#endif // IPX_AUX_KERNELS
+template <int S>
+IPX_KERNEL_WAVE_OCC(2) void k_dp_band_rev(IpxBatch b, const uint32_t *listA, const uint32_t *cnt, uint32_t *cls_off_b, uint32_t *tile_off_b, int cls)
+{
+    constexpr int D = ipx_band_d(S), WW = ipx_band_steps(S), NR = WW - S + 1;
+    const int lane = lane_id();
+    unsigned char *lds = IPX_LDS_BASE;
+    if (lane < 24) {
+        const int v = lane < 20 ? b.mat[(lane >> 2) * 5 + (lane & 3)] : -2048;
+        ((int8_t *)lds)[lane] = (int8_t)((v == -2048 ? 0xE800u : ipx_f16_from_int(v)) >> 8);
+    }
+    if (IPX_BID == 0 && lane == 0) {
+        // the full kernel's launch that follows walks listB as class `cls` of a plan of its own: 16-job tiles
+        cls_off_b[cls] = 0; cls_off_b[cls + 1] = cnt[1];
+        tile_off_b[cls] = 0; tile_off_b[cls + 1] = (cnt[1] + 15u) / 16u;
+    }
+    IPX_SYNC();
+    uint2 *ring = (uint2 *)(lds + 128) + lane;                                   // [column of the overlap][lane]
+    const uint32_t nA = cnt[0];
+    for (uint32_t base = (uint32_t)IPX_BID * 128u; base < nA; base += (uint32_t)IPX_GDIM * 128u) {    // (uniform)
+        int64_t job[2];
+        int L[2], e1[2], kmax[2], score1[2], gO[2], gE[2];
+        const int8_t *rd[2];
+        const uint32_t *refw[2];
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t slot = base + 2u * (uint32_t)lane + (uint32_t)h;
+            job[h] = -1; L[h] = 0; e1[h] = -1; kmax[h] = 0; score1[h] = 0; gO[h] = 1; gE[h] = 0;
+            rd[h] = b.reads; refw[h] = (const uint32_t *)b.refs_packed;
+            if (slot < nA) {
+                const int64_t jb = (int64_t)listA[slot];
+                const IpxResult r = b.res[jb];
+                const int rid = b.ref_id[jb];
+                job[h] = jb;
+                L[h] = r.read_end1 + 1;
+                e1[h] = r.ref_end1;
+                score1[h] = r.score1;
+                gO[h] = b.gap_open[jb]; gE[h] = b.gap_ext[jb];
+                rd[h] = b.reads + b.read_off[jb];
+                refw[h] = (const uint32_t *)(b.refs_packed + b.refp_off[rid]);
+                kmax[h] = ((b.ref_len[rid] + 3) >> 2) + 1;
+                if (!band_rev_ok(b, r, gO[h], gE[h], D) || L[h] > 8 * S || L[h] > b.f16_max_len) { atomic_or_u32(b.status, IPX_STATUS_INTERNAL); job[h] = -1; L[h] = 0; e1[h] = -1; }
+            }
+        }
+        const pk16 go = pk_make((int)ipx_f16_from_int(-gO[0]), (int)ipx_f16_from_int(-gO[1]));
+        const pk16 ge = pk_make((int)ipx_f16_from_int(-gE[0]), (int)ipx_f16_from_int(-gE[1]));
+        const pk16 term = pk_make((int)ipx_f16_from_uint((uint32_t)score1[0]), (int)ipx_f16_from_uint((uint32_t)score1[1]));
+        const pk16 live = pk_make(job[0] >= 0 ? -1 : 0, job[1] >= 0 ? -1 : 0);
+        int bcol[2] = {0x7FFFFFFF, 0x7FFFFFFF}, brow[2] = {0, 0};
+        // four letters (x 4, bytes in column order) of the group of columns starting at j0, for half h; 0x14 where there is no column
+        auto group_words = [&](int h, int j0, uint32_t &w0, uint32_t &w1) {
+            const int a0 = e1[h] - j0 - 3;
+            int wi = a0 >> 2;
+            const int top = kmax[h] > 0 ? kmax[h] - 1 : 0;          // (a half without a job: word 0 of the packed windows)
+            const int i0 = wi < 0 ? 0 : (wi > top ? top : wi), i1 = wi + 1 < 0 ? 0 : (wi + 1 > top ? top : wi + 1);
+            w0 = load_global_u32(refw[h] + i0);
+            w1 = load_global_u32(refw[h] + i1);
+        };
+        auto group_letters = [&](int h, int j0, uint32_t w0, uint32_t w1) -> uint32_t {
+            const int a0 = e1[h] - j0 - 3;
+            const uint32_t four = xl_alignbyte(w1, w0, (uint32_t)a0 & 3u);     // byte q = letter at window position a0 + q = column j0 + 3 - q
+            uint32_t x = pk_perm(0u, four << 2, 0x00010203u);                   // ... x 4, byte k = column j0 + k
+            uint32_t vm = 0;
+            IPX_UNROLL
+            for (int k = 0; k < 4; ++k)
+                if ((uint32_t)(j0 + k) <= (uint32_t)e1[h] && e1[h] >= 0) vm |= 0xFFu << (8 * k);
+            return (x & vm) | (0x14141414u & ~vm);
+        };
+        for (int q = 0; q < 8; ++q) {
+            {   // rows of this block in no read of the wave: done (padded row counts: 8 * ceil(L / 8))
+                const bool more = (job[0] >= 0 && 8 * ((L[0] + 7) >> 3) > q * S) || (job[1] >= 0 && 8 * ((L[1] + 7) >> 3) > q * S);
+                if (!xl_any(more)) break;
+            }
+            pk16 SEL[S], H[S], E[S];
+            {
+                int raw[2][S];
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    IPX_UNROLL
+                    for (int j = 0; j < S; ++j) {
+                        const int r = q * S + j;
+                        int idx = L[h] - 1 - (r < L[h] ? r : L[h] - 1);
+                        if (idx < 0) idx = 0;
+                        raw[h][j] = load_stream_i8(L[h] > 0 ? rd[h] + idx : (const int8_t *)b.read_off);
+                    }
+                }
+                IPX_UNROLL
+                for (int j = 0; j < S; ++j) {
+                    uint32_t sel = 0;
+                    IPX_UNROLL
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned bs = (unsigned)raw[h][j];
+                        uint32_t sh = 0x0c0cu;
+                        if (q * S + j < L[h] && bs < 4u) sh = 0x000cu | ((bs + 4u * h) << 8);
+                        sel |= sh << (16 * h);
+                    }
+                    SEL[j] = sel; H[j] = 0; E[j] = 0;
+                }
+            }
+            const int jbase = q * S - D;                                         // first column of the block
+            pk16 hit = 0;                                                        // halves that have found score1 in this block
+            int hcol[2] = {0, 0}, hrow[2] = {0, 0};
+            uint32_t cw[2][2], nw[2][2];
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h) { group_words(h, jbase, cw[h][0], cw[h][1]); group_words(h, jbase + 4, nw[h][0], nw[h][1]); }
+            // ring entries u and u + 1 (H of the block above's last row one column back; F leaving that row in this column), fetched a step ahead
+            uint2 r0 = q > 0 ? ring[0] : uint2{0u, 0u}, r1 = q > 0 ? ring[64] : uint2{0u, 0u};
+            uint32_t pairA, pairB, tabn0, tabn1;
+            {
+                const uint32_t x0 = group_letters(0, jbase, cw[0][0], cw[0][1]), x1 = group_letters(1, jbase, cw[1][0], cw[1][1]);
+                pairA = pk_perm(x1, x0, 0x05010400u); pairB = pk_perm(x1, x0, 0x07030602u);    // (half 0, half 1) of columns 0,1 | 2,3
+                tabn0 = *(const uint32_t *)(lds + (pairA & 0xFFu)); tabn1 = *(const uint32_t *)(lds + ((pairA >> 8) & 0xFFu));
+            }
+            for (int u0 = 0; u0 < WW; u0 += 4) {
+                // the next group's letters (their words arrived a group ago), and the request for the group after it
+                IPX_UNROLL
+                for (int h = 0; h < 2; ++h) { cw[h][0] = nw[h][0]; cw[h][1] = nw[h][1]; group_words(h, jbase + u0 + 8, nw[h][0], nw[h][1]); }
+                const uint32_t y0 = group_letters(0, jbase + u0 + 4, cw[0][0], cw[0][1]), y1 = group_letters(1, jbase + u0 + 4, cw[1][0], cw[1][1]);
+                const uint32_t nextA = pk_perm(y1, y0, 0x05010400u), nextB = pk_perm(y1, y0, 0x07030602u);
+                IPX_UNROLL
+                for (int k = 0; k < 4; ++k) {
+                    const int u = u0 + k;
+                    const uint32_t tab0 = tabn0, tab1 = tabn1;
+                    {   // the score-table words of the next step, looked up before this step's stripe
+                        const uint32_t letn = k == 3 ? nextA : (((k + 1) & 2) ? pairB : pairA) >> (((k + 1) & 1) ? 16 : 0);
+                        tabn0 = *(const uint32_t *)(lds + (letn & 0xFFu)); tabn1 = *(const uint32_t *)(lds + ((letn >> 8) & 0xFFu));
+                    }
+                    const pk16 vH = (q > 0 && u < NR) ? r0.x : 0u;
+                    pk16 vF = (q > 0 && u + 1 < NR) ? r1.y : 0u, cmx = 0;
+                    r0 = r1;
+                    if (q > 0 && u + 2 < NR) r1 = ring[(u + 2) * 64];
+                    dp_stripe_f16<S>(H, E, SEL, vF, cmx, vH, tab0, tab1, go, ge);
+                    if (u >= S - 1) ring[(u - (S - 1)) * 64] = uint2{H[S - 1], vF};
+                    const pk16 fresh = ~pk_nzmask(cmx ^ term) & live & ~hit;      // halves that reach score1 here for the first time in this block
+                    if (xl_any(fresh != 0)) {
+                        IPX_UNROLL
+                        for (int h = 0; h < 2; ++h)
+                            if ((fresh >> (16 * h)) & 0xFFFFu) {
+                                const unsigned th = (term >> (16 * h)) & 0xFFFFu;
+                                int jm = S - 1;
+                                IPX_UNROLL
+                                for (int j = S - 1; j >= 0; --j) if (((H[j] >> (16 * h)) & 0xFFFFu) == th) jm = j;
+                                hcol[h] = jbase + u; hrow[h] = q * S + jm;
+                            }
+                        hit |= fresh;
+                    }
+                }
+                pairA = nextA; pairB = nextB;
+            }
+            IPX_UNROLL
+            for (int h = 0; h < 2; ++h)
+                if (((hit >> (16 * h)) & 0xFFFFu) && hcol[h] < bcol[h]) { bcol[h] = hcol[h]; brow[h] = hrow[h]; }   // (the same column in a later block: a larger row)
+        }
+        IPX_UNROLL
+        for (int h = 0; h < 2; ++h)
+            if (job[h] >= 0) {
+                if (bcol[h] == 0x7FFFFFFF) { atomic_or_u32(b.status, IPX_STATUS_INTERNAL); continue; }   // (cannot happen: the band holds every cell with score1)
+                IpxResult r = b.res[job[h]];
+                int end_read = L[h] - 1;
+                if (brow[h] < end_read) end_read = brow[h];
+                r.ref_begin1 = e1[h] - bcol[h];                                                            // ssw.c:885
+                r.read_begin1 = r.read_end1 - end_read;                                                    // ssw.c:886
+                b.res[job[h]] = r;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_dp_wide<S, REV> (r04): the 16-bit passes (sw_sse2_word, ssw.c:410-586) of reads of 64 striped segments or more -- from 505 bp, up to
 // IPX_LONG_MAX_READ -- with gap_open > gap_ext, as ONE wavefront per read: the plain Gotoh recurrence as a wavefront over the lanes
 // (k_dp_skew: lane l owns the S consecutive rows l*S .. l*S+S-1 and works on column t - l at step t; what it needs from the lane above
@@ -3823,11 +4064,15 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 // the stepped 8-bit passes of classes 1..16 in one launch (k_dp_pass_tier)
 #define IPX_PASS_TIER_DEFINE(REV) template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #define IPX_PASS_TIER_EXTERN(REV) extern template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
+#define IPX_BAND_FAMILY(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#define IPX_BAND_DEFINE(S) template __global__ void k_dp_band_rev<S>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
+#define IPX_BAND_EXTERN(S) extern template __global__ void k_dp_band_rev<S>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
 #define IPX_WIDE_FAMILY(X) X(16, false) X(16, true) X(32, false) X(32, true) X(48, false) X(48, true) X(64, false) X(64, true)
 #define IPX_WIDE_DEFINE(S, REV) template __global__ void k_dp_wide<S, REV>(IpxBatch, IpxPlan, int, int);
 #define IPX_WIDE_EXTERN(S, REV) extern template __global__ void k_dp_wide<S, REV>(IpxBatch, IpxPlan, int, int);
 #if defined(IPX_EXTERN_KERNELS)
 IPX_WIDE_FAMILY(IPX_WIDE_EXTERN)
+IPX_BAND_FAMILY(IPX_BAND_EXTERN)
 IPX_DP_UNIT_X(IPX_LAT_EXTERN)
 IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)

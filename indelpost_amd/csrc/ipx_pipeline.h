@@ -29,7 +29,11 @@ struct IpxWorkspace {
     int long_blocks;
     int tbf_waves, tb1_waves;
     int tbd_waves;                      // blocks of a k_tb_diag launch
+    // r04, banded reverse pass (k_rev_split / k_dp_band_rev): two job lists of n_jobs slots, their counters per class (2 words each), and the class / tile
+    // offsets the full kernel's launch over the second list reads (null: no banded reverse pass)
+    uint32_t *rev_listA, *rev_listB, *rev_cnt, *rev_cls_off, *rev_tile_off;
 };
+static inline size_t ipx_rev_words(int64_t n_jobs) { return 2 * (size_t)n_jobs + 2 * IPX_NUM_CLASSES + 2 * (IPX_NUM_CLASSES + 2) + 64; }
 
 #ifndef IPX_PROVE_CHUNK_MIN_JOBS
 #define IPX_PROVE_CHUNK_MIN_JOBS 100000   // (the emulator build sets 0 so that its small batches take the queued form)
@@ -129,6 +133,10 @@ static inline bool ipx_low2_ok(const IpxBatch &b, const IpxDims &d, int routing)
 #define IPX_SUB_GENERIC 140
 #define IPX_SUB_LONG 141      // k_dp_long (reads of 64 segments or more)
 #define IPX_SUB_WIDE 142      // k_dp_wide (r04: the 16-bit passes of those reads with gap_open > gap_ext)
+#define IPX_SUB_BAND 143      // k_dp_band_rev (r04: the 16-bit reverse pass as a band)
+#ifndef IPX_BAND_MIN_TILES
+#define IPX_BAND_MIN_TILES 6000   // 16-job tiles a class needs (previous run's count) to take the banded reverse pass (the emulator build sets 0)
+#endif
 #define IPX_SUB_TIER 150      // timing sub-key of tier t: IPX_SUB_TIER + t (wavefront tiers 0..3; 8 = the stepped 8-bit tier, k_dp_pass_tier)
 
 template <class BE, int W, bool REV, int STAGE>
@@ -300,8 +308,10 @@ static void ipx_launch_dp(BE &be, const IpxBatch &b, const IpxPlan &p, const Ipx
 // the shorter classes the planner listed under its class (k_dp_skew, ROW SHIFT).  The classes of `set` that fall into one occupancy
 // (r03's shared tier launches, k_dp_skew_tier, are gone: see ipx_kernels.h.)
 template <class BE, bool REV, int BH>
-static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing, int lat = 0)
+static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, const uint8_t *set, int maxcols, int kclass, int pass, int routing, int lat = 0, const IpxWorkspace *ws_rev = nullptr)
 {
+    int banded_from = IPX_MAX_EXACT + 1;                          // classes from here on were served by the banded reverse pass
+    uint8_t todo_extra[IPX_MAX_EXACT + 1] = {0};                  // ... except these (the full kernel after all)
     if (lat && BH != 1) {
         // latency tier: LW = 32 or 64 lanes per read, the kernel with ceil(rows / LW) segments serves the class (ipx_plan_classes listed every
         // class of the pass under one)
@@ -324,8 +334,40 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
     }
     const int lds = ipx_dp_lds_bytes(8, 0, REV, maxcols, true, routing);
     const int pflag = pass | (ipx_dp_mc_in_lds(8, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
+    if constexpr (REV && BH == 0) {
+        // r04: the 16-bit reverse pass as a band where a job's score budget allows it (k_dp_band_rev; the others, through a list and a plan of
+        // their own, in the full wavefront kernel as before)
+        if (ws_rev && ws_rev->rev_listA && !(routing & IPX_ROUTE_NO_BAND_REV)) {
+            be.zero_u32(ws_rev->rev_cnt, 2 * IPX_NUM_CLASSES);
+            IpxPlan pb = p;
+            pb.perm = ws_rev->rev_listB; pb.cls_off = ws_rev->rev_cls_off; pb.tile_off = ws_rev->rev_tile_off;
+            for (int c = 8; c <= IPX_MAX_EXACT; ++c) {
+                if (!set[c]) continue;
+                const int tiles = be.dp_grid(pass, c);
+                // a band wave holds 128 jobs and lives eight blocks of ~60 steps: a class that does not fill the chip with such waves (config 4: 41 k
+                // jobs per class and stream, 0.2 waves per SIMD) only gets a longer chain of launches out of it -- 57.9 -> 56.6 M aln/s; 2b: 85.3 -> 94.4
+                if (tiles < IPX_BAND_MIN_TILES && !(routing & IPX_ROUTE_FORCE_BAND_REV)) { todo_extra[c] = 1; continue; }                          // (sized from the previous run's tile count of the class)
+                int gs = tiles / 32 + 1, gb = tiles / 8 + 1;                   // 512 jobs per block of the split, 128 per block of the band
+                uint32_t *cnt = ws_rev->rev_cnt + 2 * c;
+                be.launch(IPX_KEY(IPX_K_PLAN, 6), k_rev_split, gs, 64, 0, b, p, c, ws_rev->rev_listA, ws_rev->rev_listB, cnt);
+                be.note_dp(IPX_KEY(kclass, c), pass, c, 16);
+                be.note_f16(1, c);
+#define IPX_BAND_CASE(C) case C: be.launch(IPX_KEY(kclass, IPX_SUB_BAND), k_dp_band_rev<C>, gb, 64, ipx_band_lds_bytes(C), b, (const uint32_t *)ws_rev->rev_listA, (const uint32_t *)cnt, ws_rev->rev_cls_off, ws_rev->rev_tile_off, c); \
+                           be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), true, 0>, tiles, 64, lds, b, pb, c, maxcols, pflag); break;
+                switch (c) {
+                    IPX_BAND_CASE(8) IPX_BAND_CASE(9) IPX_BAND_CASE(10) IPX_BAND_CASE(11) IPX_BAND_CASE(12) IPX_BAND_CASE(13) IPX_BAND_CASE(14) IPX_BAND_CASE(15)
+                    IPX_BAND_CASE(16) IPX_BAND_CASE(17) IPX_BAND_CASE(18) IPX_BAND_CASE(19) IPX_BAND_CASE(20) IPX_BAND_CASE(21) IPX_BAND_CASE(22) IPX_BAND_CASE(23)
+                    IPX_BAND_CASE(24) IPX_BAND_CASE(25) IPX_BAND_CASE(26) IPX_BAND_CASE(27) IPX_BAND_CASE(28) IPX_BAND_CASE(29) IPX_BAND_CASE(30) IPX_BAND_CASE(31)
+                    IPX_BAND_CASE(32)
+                default: break;
+                }
+#undef IPX_BAND_CASE
+            }
+            banded_from = 8;
+        }
+    }
     uint8_t todo[IPX_MAX_EXACT + 1];
-    for (int c = 0; c <= IPX_MAX_EXACT; ++c) todo[c] = c <= (BH ? 16 : IPX_MAX_EXACT) ? set[c] : 0;
+    for (int c = 0; c <= IPX_MAX_EXACT; ++c) todo[c] = (c <= (BH ? 16 : IPX_MAX_EXACT) && (c < banded_from || todo_extra[c])) ? set[c] : 0;
     for (int c = 0; c <= (BH ? 16 : IPX_MAX_EXACT); ++c) {
         if (!todo[c]) continue;
         be.note_dp(IPX_KEY(kclass, c), pass, c, 16);
@@ -497,7 +539,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
         }
         if (b.score_size != 0 && !skip(IPX_PASS_WORD_REV)) {
             ipx_plan_pass(be, b, ws.plan[IPX_PASS_WORD_REV], IPX_PASS_WORD_REV, ipx_skew_na(d));
-            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, d.lat);
+            if (d.word_sets) ipx_launch_skew_set<BE, true, 0>(be, b, ws.plan[IPX_PASS_WORD_REV], d.set[IPX_PASS_WORD_REV], maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, d.lat, &ws);
             ipx_launch_dp<BE, 8, true, IPX_STAGE_EXACT>(be, b, ws.plan[IPX_PASS_WORD_REV], ws, has16_all, maxcols, IPX_K_WORD_REV, IPX_PASS_WORD_REV, routing, 3, word_from, 16);
         }
         if ((7 & b.flag) != 0) {                                 // CIGAR (ssw.c:894-916)

@@ -74,7 +74,7 @@ struct ipx_ctx {
     bool have_mask = false;
     DevBuf reads, read_off, refs_raw, ref_off, refs_packed, refp_off, ref_len, ref_id, gap_open, gap_ext, mask_len;
     DevBuf res, cigar_pool, small;     // small: cursor, status, plan tables, list counters
-    DevBuf perm, tb_list, tb_esc, tb_bw, tb1, maxcol, tbf, long_state;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
+    DevBuf perm, tb_list, tb_esc, tb_bw, tb1, maxcol, tbf, long_state, rev;     // perm: three job lists of n_jobs (two static passes + one shared by the dynamic ones)
     uint32_t cigar_cap = 0;
     IpxWorkspace ws;
     IpxBatch batch;
@@ -263,7 +263,7 @@ void ipx_destroy(ipx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->reads, &c->read_off, &c->refs_raw, &c->ref_off, &c->refs_packed, &c->refp_off, &c->ref_len,
                       &c->ref_id, &c->gap_open, &c->gap_ext, &c->mask_len, &c->res, &c->cigar_pool, &c->small, &c->perm,
-                      &c->tb_list, &c->tb_esc, &c->tb_bw, &c->tb1, &c->maxcol, &c->tbf, &c->long_state})
+                      &c->tb_list, &c->tb_esc, &c->tb_bw, &c->tb1, &c->maxcol, &c->tbf, &c->long_state, &c->rev})
         b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->run_start);
@@ -475,6 +475,12 @@ int ipx_upload(ipx_ctx *c, const int8_t *reads, const int64_t *read_off, const i
     b.maxcol_scratch = c->maxcol.as<uint32_t>();
     b.tb_bw = c->tb_bw.as<uint16_t>();
     c->ws.tbd_waves = c->num_cu * 8;                         // k_tb_diag: 21 KB of LDS per one-wave block, seven resident per CU
+    {   // banded reverse pass: two job lists, counters per class, the second list's class / tile offsets
+        if (c->rev.ensure(4 * ipx_rev_words(n_jobs))) return IPX_ERR_NO_DEVICE;
+        uint32_t *rv = c->rev.as<uint32_t>();
+        c->ws.rev_listA = rv; c->ws.rev_listB = rv + n_jobs; c->ws.rev_cnt = rv + 2 * (size_t)n_jobs;
+        c->ws.rev_cls_off = c->ws.rev_cnt + 2 * IPX_NUM_CLASSES; c->ws.rev_tile_off = c->ws.rev_cls_off + IPX_NUM_CLASSES + 2;
+    }
     if (!c->async_io) HIPCHK(hipStreamSynchronize(s));
     c->n_jobs = n_jobs; c->n_refs = n_refs;
     return IPX_OK;

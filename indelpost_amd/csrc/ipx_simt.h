@@ -105,6 +105,8 @@ IPX_DEV uint32_t pk_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 }
 // per half: the signed high byte, sign-extended to 16 bit (v_pk_ashrrev_i16 by 8)
 IPX_DEV pk16 pk_sext_hi8(pk16 x) { return pk_make(pk_lo(x) >> 8, pk_hi(x) >> 8); }
+// v_alignbyte_b32: four consecutive bytes of the eight-byte value {hi:lo}, starting at byte sh & 3
+IPX_DEV uint32_t xl_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3u))) & 0xFFFFFFFFu); }
 IPX_DEV int8_t load_stream_i8(const int8_t *p) { return *p; }
 IPX_DEV uint32_t load_global_u32(const uint32_t *p) { return *p; }
 IPX_DEV void store_global_u32(uint32_t *p, uint32_t v) { *p = v; }
@@ -217,6 +219,7 @@ IPX_DEV pk16 pk_subus(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_sub_
 IPX_DEV pk16 pk_max(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_max(IPX_S2(a), IPX_S2(b))); }            // v_pk_max_i16
 IPX_DEV pk16 pk_minu(pk16 a, pk16 b) { return IPX_PK(__builtin_elementwise_min(IPX_U2(a), IPX_U2(b))); }           // v_pk_min_u16
 IPX_DEV pk16 pk_sext_hi8(pk16 x) { return IPX_PK(IPX_S2(x) >> 8); }   // per half: signed high byte -> 16 bit: v_pk_ashrrev_i16
+IPX_DEV uint32_t xl_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }   // v_alignbyte_b32
 IPX_DEV pk16 pk_mul(pk16 a, pk16 b) { return IPX_PK(IPX_U2(a) * IPX_U2(b)); }                                     // v_pk_mul_lo_u16
 IPX_DEV pk16 pk_shr1(pk16 a) { return IPX_PK(IPX_U2(a) >> 1); }                                                    // v_pk_lshrrev_b16
 IPX_DEV uint32_t ubfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }

@@ -97,6 +97,8 @@ enum {
     IPX_ROUTE_NO_SETPRIO = 4194304,       // the latency-bound kernels keep the default wave priority
     IPX_ROUTE_TB_PER_WIDTH = 8388608,     // big batches: one lane-per-job traceback launch per band width 1, 2, 3 and one for 4..7, a doubled band served by the next width's launch (r02..r04; default: one launch, its blocks shared out on the device)
     IPX_ROUTE_REV_BELOW = 16777216,       // the reverse passes launch class c - 1 beside every forward class c (r03; default: prefixes of class c - 1 ride in c's launch)
+    IPX_ROUTE_NO_BAND_REV = 33554432,     // the 16-bit reverse pass over the whole prefix rectangle for every job (default: as a band where the job's score budget allows)
+    IPX_ROUTE_FORCE_BAND_REV = 67108864,  // (testing) the banded reverse pass whatever the size of the class
     IPX_ROUTE_FORCE_LAT = 65536,          // (testing) the latency tier whatever the batch size, where its other conditions hold
     IPX_ROUTE_INTERNAL_VL2 = 1 << 20,   // (set by ipx_run_pipeline itself: the lower-bound launches of this run take the VL2 kernels)
 };

@@ -284,6 +284,11 @@ extern "C" int emu_align_batch(const int8_t *reads, const int64_t *read_off, con
     ws.tb1.cig = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)s1.cigcap * ws.tb1_waves + 64);
     memset(ws.tb1.dir, 0x5A, (size_t)s1.dircap * ws.tb1_waves);
 
+    {   // banded reverse pass: two job lists, counters per class, the second list's class / tile offsets
+        uint32_t *rv = zalloc<uint32_t>(ipx_rev_words(n_jobs));
+        ws.rev_listA = rv; ws.rev_listB = rv + n_jobs; ws.rev_cnt = rv + 2 * (size_t)n_jobs;
+        ws.rev_cls_off = ws.rev_cnt + 2 * IPX_NUM_CLASSES; ws.rev_tile_off = ws.rev_cls_off + IPX_NUM_CLASSES + 2;
+    }
     ws.long_state = nullptr; ws.long_stride = 0; ws.long_blocks = 0;
     if (d.max_read_len > 8 * (IPX_MAX_SEG - 1)) {          // class 64 ("64 segments or more") can occur: from 505 bp in the 16-bit passes
         ws.long_stride = (int64_t)ipx_long_state_bytes(d.max_read_len);

@@ -27,7 +27,7 @@ def build_emu(force=False):
     if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_LIB) for s in srcs):
         return EMU_LIB
     # (-g doubles the compile time of this one big translation unit: only on request, IPX_EMU_DEBUG=1)
-    subprocess.check_call(["g++", "-O1"] + (["-g"] if os.environ.get("IPX_EMU_DEBUG") else []) + ["-std=c++17", "-DIPX_CPU_EMU", "-DIPX_PROVE_CHUNK_MIN_JOBS=0", "-DIPX_MERGE_BELOW=6", "-DIPX_MERGE_TINY=2", "-DIPX_LAT_MAX_JOBS=0", "-DIPX_TB_SMALL_DIAG=2048", "-DIPX_TB_TINY_DIAG=60", "-fPIC", "-shared",
+    subprocess.check_call(["g++", "-O1"] + (["-g"] if os.environ.get("IPX_EMU_DEBUG") else []) + ["-std=c++17", "-DIPX_CPU_EMU", "-DIPX_PROVE_CHUNK_MIN_JOBS=0", "-DIPX_MERGE_BELOW=6", "-DIPX_MERGE_TINY=2", "-DIPX_LAT_MAX_JOBS=0", "-DIPX_BAND_MIN_TILES=0", "-DIPX_TB_SMALL_DIAG=2048", "-DIPX_TB_TINY_DIAG=60", "-fPIC", "-shared",
                            "-U_FORTIFY_SOURCE", "-Wall", "-Wno-unused-function", "-o", EMU_LIB, srcs[0]])
     return EMU_LIB
 

@@ -493,6 +493,57 @@ def test_emu_long_reads_one_wavefront_per_read(emu, oracle_mod, port):
     assert res2.records.tobytes() == res.records.tobytes() and res2.cigar_pool.tobytes() == res.cigar_pool.tobytes()
 
 
+def test_emu_reverse_pass_as_a_band(emu, oracle_mod, port):
+    """r04, k_rev_split / k_dp_band_rev: the 16-bit reverse pass of a job whose score budget bounds its drift from the end cell's diagonal by
+    the class's band half-width (segments + 1: 20 for 150 bp) is computed inside that band, one lane per pair of reads, block of rows after block of rows; the other jobs take the full
+    wavefront kernel through a list of their own.  Clean reads, reads with junk in front of / behind the aligned part (the begin cell is not
+    row 0, the end cell not the last base), short and long indels (inside and beyond the band), noise, N, gap_ext 0 and 2, read lengths across
+    several classes and windows shorter than the reads; every field and CIGAR against the oracle; the same records with the band switched off."""
+    rng = np.random.default_rng(2020)
+    w = rng.integers(0, 4, 420).astype(np.int8)
+    w2 = rng.integers(0, 4, 110).astype(np.int8)
+    reads, rid, go, ge = [], [], [], []
+    for i in range(150):
+        win = w2 if i % 7 == 6 else w
+        ln = int(rng.choice([66, 70, 100, 104, 128, 150, 152, 200, 250, 256])) if win is w else int(rng.choice([70, 90, 100]))
+        st = int(rng.integers(0, max(1, len(win) - ln)))
+        r = np.resize(win[st:], ln).copy()
+        kind = i % 10
+        if kind in (1, 2):
+            m = rng.random(ln) < (0.01, 0.06)[kind - 1]
+            r[m] = rng.integers(0, 5, int(m.sum()))
+        if kind == 3:
+            r = np.concatenate([r[:ln // 2], r[ln // 2 + int(rng.integers(1, 9)):]])
+        if kind == 4:
+            r = np.concatenate([r[:ln // 3], rng.integers(0, 4, int(rng.integers(1, 9))).astype(np.int8), r[ln // 3:]])
+        if kind == 5:
+            r = np.concatenate([r[:ln // 2], r[ln // 2 + int(rng.integers(22, 40)):]])                # a deletion beyond the band
+        if kind == 6:
+            r = np.concatenate([rng.integers(0, 4, int(rng.integers(5, 30))).astype(np.int8), r[10:]])  # junk in front: the alignment begins inside the read
+        if kind == 7:
+            r = np.concatenate([r[:-12], rng.integers(0, 4, int(rng.integers(5, 25))).astype(np.int8)])  # junk behind
+        if kind == 8:
+            r = rng.integers(0, 4, ln).astype(np.int8)                                               # noise
+        reads.append(r[:256]); rid.append(1 if win is w2 else 0)
+        g = [(3, 1), (5, 2), (4, 1), (3, 0), (6, 1), (2, 1)][i % 6]
+        go.append(g[0]); ge.append(g[1])
+    jobs = JobTable.from_sequences(reads, [w, w2], rid, go, ge, encoded=True)
+    for ms, mm in ((3, 2), (5, 4)):
+        a = emu(0, ms, mm)
+        res = a.align(jobs)
+        assert a.status == 0
+        _compare(res, [(r, (w, w2)[k], o_, e_) for r, k, o_, e_ in zip(reads, rid, go, ge)], port, oracle_mod.dna_matrix(ms, mm))
+        band = sum(n for k, n in a.launches.items() if k // 256 == K_WORD_REV and k % 256 == 143)
+        assert band >= 4                                                      # several classes took the band kernel ...
+        assert any(n for k, n in a.launches.items() if k // 256 == K_WORD_REV and 8 <= k % 256 <= 32)      # ... and the full kernel its leftovers
+        o = emu(0, ms, mm)
+        o.set_routing(R.ROUTE_NO_BAND_REV)
+        res2 = o.align(jobs)
+        assert o.status == 0 and not any(k % 256 == 143 for k in o.launches)
+        assert res2.records.tobytes() == res.records.tobytes() and res2.cigar_pool.tobytes() == res.cigar_pool.tobytes()
+    assert ((res.records["read_begin1"] > 0) & (res.records["mode"] == 1)).sum() >= 5      # alignments that begin inside the read were among them
+
+
 def test_emu_anti_diagonal_traceback_tiers(emu, oracle_mod, port):
     """r04, k_tb_diag<16 / 32 / 64>: banded_sw as an anti-diagonal wavefront.  Jobs whose first band |refLen - readLen| + 1 runs from 1 to
     ~90 (deletions and insertions of 1..90 bp bridged under cheap gap extension), compensating indels that make a band double inside
