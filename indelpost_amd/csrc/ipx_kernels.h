@@ -1857,7 +1857,10 @@ IPX_KERNEL_WAVE_OCC(W == 8 ? ipx_skew_waves(SMAX, REV) : 1) void k_dp_skew(IpxBa
 // Dynamic LDS: 128 B score table | ring of (WW - S + 1) x 64 lanes x 8 B
 // ------------------------------------------------------------------------------------------------
 // half-width of the band of class S: errors, and with them the budget, grow with the read's length (2b, 150 bp, D = 20: 72 % of the jobs eligible)
-IPX_HD constexpr int ipx_band_d(int S) { return S + 1; }
+#ifndef IPX_BAND_DX
+#define IPX_BAND_DX 1
+#endif
+IPX_HD constexpr int ipx_band_d(int S) { return S + IPX_BAND_DX; }
 IPX_HD constexpr int ipx_band_steps(int S) { return (S + 2 * ipx_band_d(S) + 1 + 3) & ~3; }
 static inline int ipx_band_lds_bytes(int S) { return 128 + (ipx_band_steps(S) - S + 1) * 64 * 8; }
 IPX_DEV bool band_rev_ok(const IpxBatch &b, const IpxResult &r, int gO, int gE, int D)
