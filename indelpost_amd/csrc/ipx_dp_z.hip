@@ -3,3 +3,4 @@
 #define IPX_DP_TEMPLATES_ONLY 1
 #include "ipx_kernels.h"
 IPX_BAND_FAMILY(IPX_BAND_DEFINE)
+IPX_BAND8_FAMILY(IPX_BAND8_DEFINE)

@@ -1873,7 +1873,7 @@ IPX_DEV bool band_rev_ok(const IpxBatch &b, const IpxResult &r, int gO, int gE, 
 }
 #if IPX_AUX_KERNELS
 // the jobs of class `cls` of the reverse pass's list, sorted into those the band serves (listA) and the others (listB); cnt[0..1]: their numbers
-IPX_KERNEL_WAVE void k_rev_split(IpxBatch b, IpxPlan p, int cls, uint32_t *listA, uint32_t *listB, uint32_t *cnt)
+IPX_KERNEL_WAVE void k_rev_split(IpxBatch b, IpxPlan p, int cls, int D, uint32_t *listA, uint32_t *listB, uint32_t *cnt)
 {
     IPX_RAISE_PRIO(b);
     constexpr int R = 8;                                            // jobs per lane and round of the wave: ONE pair of atomics per 512 jobs
@@ -1890,7 +1890,7 @@ IPX_KERNEL_WAVE void k_rev_split(IpxBatch b, IpxPlan p, int cls, uint32_t *listA
             in[k] = at < n; a[k] = false; job[k] = 0;
             if (in[k]) {
                 job[k] = p.perm[lo + at];
-                a[k] = band_rev_ok(b, b.res[job[k]], b.gap_open[job[k]], b.gap_ext[job[k]], ipx_band_d(cls));
+                a[k] = band_rev_ok(b, b.res[job[k]], b.gap_open[job[k]], b.gap_ext[job[k]], D);
             }
             const uint64_t ma = xl_ballot(in[k] && a[k]), mb = xl_ballot(in[k] && !a[k]);
             pa[k] = na + (uint32_t)__builtin_popcountll(ma & below); pb[k] = nb + (uint32_t)__builtin_popcountll(mb & below);
@@ -1910,7 +1910,9 @@ IPX_KERNEL_WAVE void k_rev_split(IpxBatch b, IpxPlan p, int cls, uint32_t *listA
     }
 }
 #endif // IPX_AUX_KERNELS
-template <int S>
+// BH = 2: the plain recurrence in the 8-bit dialect (IPX_PASS_BYTE_REV_PLAIN: the reverse pass of reads whose 8-bit forward result equals the plain
+// recurrence's, k_dp_skew BH = 2) -- the same band, S = 2 x the 8-bit class; afterwards the begin cell is final below 128 and k_prove_plain's otherwise
+template <int S, int BH = 0>
 IPX_KERNEL_WAVE_OCC(2) void k_dp_band_rev(IpxBatch b, const uint32_t *listA, const uint32_t *cnt, uint32_t *cls_off_b, uint32_t *tile_off_b, int cls)
 {
     constexpr int D = ipx_band_d(S), WW = ipx_band_steps(S), NR = WW - S + 1;
@@ -1979,7 +1981,8 @@ IPX_KERNEL_WAVE_OCC(2) void k_dp_band_rev(IpxBatch b, const uint32_t *listA, con
         };
         for (int q = 0; q < 8; ++q) {
             {   // rows of this block in no read of the wave: done (padded row counts: 8 * ceil(L / 8))
-                const bool more = (job[0] >= 0 && 8 * ((L[0] + 7) >> 3) > q * S) || (job[1] >= 0 && 8 * ((L[1] + 7) >> 3) > q * S);
+                const bool more = (job[0] >= 0 && (BH ? 16 * ((L[0] + 15) >> 4) : 8 * ((L[0] + 7) >> 3)) > q * S) ||
+                                  (job[1] >= 0 && (BH ? 16 * ((L[1] + 15) >> 4) : 8 * ((L[1] + 7) >> 3)) > q * S);
                 if (!xl_any(more)) break;
             }
             pk16 SEL[S], H[S], E[S];
@@ -2071,6 +2074,7 @@ IPX_KERNEL_WAVE_OCC(2) void k_dp_band_rev(IpxBatch b, const uint32_t *listA, con
                 if (brow[h] < end_read) end_read = brow[h];
                 r.ref_begin1 = e1[h] - bcol[h];                                                            // ssw.c:885
                 r.read_begin1 = r.read_end1 - end_read;                                                    // ssw.c:886
+                if (BH == 2) r.mode = score1[h] < 128 ? IPX_MODE_BYTE : IPX_MODE_NEED_REV_PROOF;           // (as k_dp_skew BH = 2)
                 b.res[job[h]] = r;
             }
     }
@@ -4068,14 +4072,18 @@ IPX_KERNEL_WAVE void k_tb_diag(IpxBatch b, const uint32_t *list, const uint32_t 
 #define IPX_PASS_TIER_DEFINE(REV) template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #define IPX_PASS_TIER_EXTERN(REV) extern template __global__ void k_dp_pass_tier<16, IPX_PASS_TIER_LO, IPX_PASS_TIER_HI, REV, IPX_STAGE_EXACT>(IpxBatch, IpxPlan, uint32_t, int, int);
 #define IPX_BAND_FAMILY(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
-#define IPX_BAND_DEFINE(S) template __global__ void k_dp_band_rev<S>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
-#define IPX_BAND_EXTERN(S) extern template __global__ void k_dp_band_rev<S>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
+#define IPX_BAND_DEFINE(S) template __global__ void k_dp_band_rev<S, 0>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
+#define IPX_BAND_EXTERN(S) extern template __global__ void k_dp_band_rev<S, 0>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
+#define IPX_BAND8_FAMILY(X) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+#define IPX_BAND8_DEFINE(S) template __global__ void k_dp_band_rev<S, 2>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
+#define IPX_BAND8_EXTERN(S) extern template __global__ void k_dp_band_rev<S, 2>(IpxBatch, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, int);
 #define IPX_WIDE_FAMILY(X) X(16, false) X(16, true) X(32, false) X(32, true) X(48, false) X(48, true) X(64, false) X(64, true)
 #define IPX_WIDE_DEFINE(S, REV) template __global__ void k_dp_wide<S, REV>(IpxBatch, IpxPlan, int, int);
 #define IPX_WIDE_EXTERN(S, REV) extern template __global__ void k_dp_wide<S, REV>(IpxBatch, IpxPlan, int, int);
 #if defined(IPX_EXTERN_KERNELS)
 IPX_WIDE_FAMILY(IPX_WIDE_EXTERN)
 IPX_BAND_FAMILY(IPX_BAND_EXTERN)
+IPX_BAND8_FAMILY(IPX_BAND8_EXTERN)
 IPX_DP_UNIT_X(IPX_LAT_EXTERN)
 IPX_PASS_TIER_EXTERN(false) IPX_PASS_TIER_EXTERN(true)
 IPX_DP_UNIT_K(IPX_SKEW_EXTERN) IPX_DP_UNIT_L(IPX_SKEW_EXTERN)

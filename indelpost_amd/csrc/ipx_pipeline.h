@@ -334,27 +334,34 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
     }
     const int lds = ipx_dp_lds_bytes(8, 0, REV, maxcols, true, routing);
     const int pflag = pass | (ipx_dp_mc_in_lds(8, REV, maxcols, true, routing) ? IPX_PASS_MC_LDS : 0);
-    if constexpr (REV && BH == 0) {
-        // r04: the 16-bit reverse pass as a band where a job's score budget allows it (k_dp_band_rev; the others, through a list and a plan of
-        // their own, in the full wavefront kernel as before)
+    if constexpr (REV && BH != 1) {
+        // r04: the reverse pass as a band where a job's score budget allows it (k_dp_band_rev; the others, through a list and a plan of their own, in
+        // the full wavefront kernel as before).  BH = 2, the plain recurrence in the 8-bit dialect: class c = 2 c segments.
         if (ws_rev && ws_rev->rev_listA && !(routing & IPX_ROUTE_NO_BAND_REV)) {
             be.zero_u32(ws_rev->rev_cnt, 2 * IPX_NUM_CLASSES);
             IpxPlan pb = p;
             pb.perm = ws_rev->rev_listB; pb.cls_off = ws_rev->rev_cls_off; pb.tile_off = ws_rev->rev_tile_off;
-            for (int c = 8; c <= IPX_MAX_EXACT; ++c) {
+            const int c_lo = BH ? 4 : 8, c_hi = BH ? 16 : IPX_MAX_EXACT;
+            for (int c = c_lo; c <= c_hi; ++c) {
                 if (!set[c]) continue;
-                const int tiles = be.dp_grid(pass, c);
+                const int tiles = be.dp_grid(pass, c);                          // (sized from the previous run's tile count of the class)
                 // a band wave holds 128 jobs and lives eight blocks of ~60 steps: a class that does not fill the chip with such waves (config 4: 41 k
                 // jobs per class and stream, 0.2 waves per SIMD) only gets a longer chain of launches out of it -- 57.9 -> 56.6 M aln/s; 2b: 85.3 -> 94.4
-                if (tiles < IPX_BAND_MIN_TILES && !(routing & IPX_ROUTE_FORCE_BAND_REV)) { todo_extra[c] = 1; continue; }                          // (sized from the previous run's tile count of the class)
+                if (tiles < IPX_BAND_MIN_TILES && !(routing & IPX_ROUTE_FORCE_BAND_REV)) { todo_extra[c] = 1; continue; }
                 int gs = tiles / 32 + 1, gb = tiles / 8 + 1;                   // 512 jobs per block of the split, 128 per block of the band
                 uint32_t *cnt = ws_rev->rev_cnt + 2 * c;
-                be.launch(IPX_KEY(IPX_K_PLAN, 6), k_rev_split, gs, 64, 0, b, p, c, ws_rev->rev_listA, ws_rev->rev_listB, cnt);
+                be.launch(IPX_KEY(IPX_K_PLAN, 6), k_rev_split, gs, 64, 0, b, p, c, ipx_band_d(BH ? 2 * c : c), ws_rev->rev_listA, ws_rev->rev_listB, cnt);
                 be.note_dp(IPX_KEY(kclass, c), pass, c, 16);
-                be.note_f16(1, c);
-#define IPX_BAND_CASE(C) case C: be.launch(IPX_KEY(kclass, IPX_SUB_BAND), k_dp_band_rev<C>, gb, 64, ipx_band_lds_bytes(C), b, (const uint32_t *)ws_rev->rev_listA, (const uint32_t *)cnt, ws_rev->rev_cls_off, ws_rev->rev_tile_off, c); \
-                           be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), true, 0>, tiles, 64, lds, b, pb, c, maxcols, pflag); break;
+                be.note_f16(BH ? 2 : 1, BH ? 2 * c : c);
+#define IPX_BAND_CASE(C) case C: if constexpr (BH == 0 && (C) >= 8) { \
+                               be.launch(IPX_KEY(kclass, IPX_SUB_BAND), k_dp_band_rev<(C), 0>, gb, 64, ipx_band_lds_bytes(C), b, (const uint32_t *)ws_rev->rev_listA, (const uint32_t *)cnt, ws_rev->rev_cls_off, ws_rev->rev_tile_off, c); \
+                               be.launch(IPX_KEY(kclass, c), k_dp_skew<(C), true, 0>, tiles, 64, lds, b, pb, c, maxcols, pflag); \
+                           } else if constexpr (BH == 2 && (C) <= 16) { \
+                               be.launch(IPX_KEY(kclass, IPX_SUB_BAND), k_dp_band_rev<2 * (C), 2>, gb, 64, ipx_band_lds_bytes(2 * (C)), b, (const uint32_t *)ws_rev->rev_listA, (const uint32_t *)cnt, ws_rev->rev_cls_off, ws_rev->rev_tile_off, c); \
+                               be.launch(IPX_KEY(kclass, c), k_dp_skew<2 * (C), true, 2>, tiles, 64, lds, b, pb, c, maxcols, pflag); \
+                           } break;
                 switch (c) {
+                    IPX_BAND_CASE(4) IPX_BAND_CASE(5) IPX_BAND_CASE(6) IPX_BAND_CASE(7)
                     IPX_BAND_CASE(8) IPX_BAND_CASE(9) IPX_BAND_CASE(10) IPX_BAND_CASE(11) IPX_BAND_CASE(12) IPX_BAND_CASE(13) IPX_BAND_CASE(14) IPX_BAND_CASE(15)
                     IPX_BAND_CASE(16) IPX_BAND_CASE(17) IPX_BAND_CASE(18) IPX_BAND_CASE(19) IPX_BAND_CASE(20) IPX_BAND_CASE(21) IPX_BAND_CASE(22) IPX_BAND_CASE(23)
                     IPX_BAND_CASE(24) IPX_BAND_CASE(25) IPX_BAND_CASE(26) IPX_BAND_CASE(27) IPX_BAND_CASE(28) IPX_BAND_CASE(29) IPX_BAND_CASE(30) IPX_BAND_CASE(31)
@@ -363,7 +370,7 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
                 }
 #undef IPX_BAND_CASE
             }
-            banded_from = 8;
+            banded_from = c_lo;
         }
     }
     uint8_t todo[IPX_MAX_EXACT + 1];
@@ -529,7 +536,7 @@ static void ipx_run_pipeline(BE &be, const IpxBatch &b, const IpxWorkspace &ws, 
             if (d.plain_first && !skip(IPX_PASS_BYTE_REV_PLAIN)) {
                 // reads whose forward result equals the plain recurrence's: plain reverse recurrence, certified by proof
                 ipx_plan_pass(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], IPX_PASS_BYTE_REV_PLAIN, ipx_skew_na(d));
-                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing, d.lat);
+                ipx_launch_skew_set<BE, true, 2>(be, b, ws.plan[IPX_PASS_BYTE_REV_PLAIN], d.set[IPX_PASS_BYTE_REV_PLAIN], maxcols, IPX_K_BYTE_REV_PLAIN, IPX_PASS_BYTE_REV_PLAIN, routing, d.lat, &ws);
                 be.launch(IPX_KEY(IPX_K_PROVE_PLAIN, 1), k_prove_plain<true>, prove_grid2, 64, ipx_prove_lds_bytes(4 * 64 * IPX_PROVE_EXT), b, prove_chunk);
             }
             if (!skip(IPX_PASS_BYTE_REV)) {

@@ -85,7 +85,9 @@ def _make_jobs(rng, n_jobs, n_refs, alpha_mix=True, fast_gaps_only=False):
                                            # r04: the 16-bit reverse pass as a band (k_dp_band_rev) whatever the size of the class -- in a batch of 30 000 no class has the
                                            # 6 000 tiles that switch it on by itself; and switched off
                                            ((3, 2), (R.ROUTE_FORCE_BAND_REV,)), ((3, 2), (R.ROUTE_FORCE_BAND_REV, "fast_gaps")), ((5, 4), (R.ROUTE_FORCE_BAND_REV, "fast_gaps")),
-                                           ((7, 8), (R.ROUTE_FORCE_BAND_REV,)), ((2, 4), (R.ROUTE_FORCE_BAND_REV, "fast_gaps")), ((3, 2), (R.ROUTE_NO_BAND_REV, "fast_gaps"))])
+                                           ((7, 8), (R.ROUTE_FORCE_BAND_REV,)), ((2, 4), (R.ROUTE_FORCE_BAND_REV, "fast_gaps")), ((3, 2), (R.ROUTE_NO_BAND_REV, "fast_gaps")),
+                                           # ... and of the plain recurrence in the 8-bit dialect
+                                           ((1, 1), (R.ROUTE_FORCE_BAND_REV, "fast_gaps")), ((2, 2), (R.ROUTE_FORCE_BAND_REV,)), ((1, 3), (R.ROUTE_FORCE_BAND_REV, "fast_gaps"))])
 def test_gpu_stress_vs_cpu_checker(gpu, oracle_mod, scoring, knobs, capfd):
     from oracle.oracle import cpu_batch_results, fnv1a_ops
     fast = "fast_gaps" in knobs
