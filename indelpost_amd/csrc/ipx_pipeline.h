@@ -347,7 +347,8 @@ static void ipx_launch_skew_set(BE &be, const IpxBatch &b, const IpxPlan &p, con
                 const int tiles = be.dp_grid(pass, c);                          // (sized from the previous run's tile count of the class)
                 // a band wave holds 128 jobs and lives eight blocks of ~60 steps: a class that does not fill the chip with such waves (config 4: 41 k
                 // jobs per class and stream, 0.2 waves per SIMD) only gets a longer chain of launches out of it -- 57.9 -> 56.6 M aln/s; 2b: 85.3 -> 94.4
-                if (tiles < IPX_BAND_MIN_TILES && !(routing & IPX_ROUTE_FORCE_BAND_REV)) { todo_extra[c] = 1; continue; }
+                // (a context's first run has no tile counts yet and sizes every launch for the whole batch: the batch's own size bounds the class then)
+                if ((tiles < IPX_BAND_MIN_TILES || b.n_jobs / 16 < IPX_BAND_MIN_TILES) && !(routing & IPX_ROUTE_FORCE_BAND_REV)) { todo_extra[c] = 1; continue; }
                 int gs = tiles / 32 + 1, gb = tiles / 8 + 1;                   // 512 jobs per block of the split, 128 per block of the band
                 uint32_t *cnt = ws_rev->rev_cnt + 2 * c;
                 be.launch(IPX_KEY(IPX_K_PLAN, 6), k_rev_split, gs, 64, 0, b, p, c, ipx_band_d(BH ? 2 * c : c), ws_rev->rev_listA, ws_rev->rev_listB, cnt);
