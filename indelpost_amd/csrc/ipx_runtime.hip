@@ -698,6 +698,7 @@ const char *ipx_kernel_class_name(int k)
         if (sub == IPX_SUB_GENERIC) snprintf(buf, sizeof buf, "%s_long", k_names[kc]);
         else if (sub == IPX_SUB_LONG) snprintf(buf, sizeof buf, "%s_kb_loops", k_names[kc]);      // k_dp_long: reads of 64 segments or more, the transcribed loops
         else if (sub == IPX_SUB_WIDE) snprintf(buf, sizeof buf, "%s_kb_wavefront", k_names[kc]);  // k_dp_wide: ... one wavefront per read
+        else if (sub == IPX_SUB_BAND) snprintf(buf, sizeof buf, "%s_band", k_names[kc]);          // k_dp_band_rev: the reverse pass as a band (every class of the pass)
         else if (sub >= IPX_SUB_TIER) snprintf(buf, sizeof buf, "%s_tier%d", k_names[kc], sub - IPX_SUB_TIER);
         else if (sub >= IPX_SLOW_BASE) snprintf(buf, sizeof buf, "%s_slowgap_s%d", k_names[kc], sub - IPX_SLOW_BASE);
         else snprintf(buf, sizeof buf, "%s_s%d", k_names[kc], sub);
