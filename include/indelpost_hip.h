@@ -198,6 +198,14 @@ int64_t ipx_format_cigars(const ipx_result *rec, const uint32_t *cigar_pool, int
 int ipx_concat_sizes(const int64_t *desc, int64_t n_tables, int64_t *totals);
 int ipx_concat_tables(const int64_t *desc, int64_t n_tables, int8_t *reads, int64_t *read_off, int8_t *refs, int64_t *ref_off, int32_t *ref_id,
                       uint8_t *gap_open, uint8_t *gap_ext, int32_t *mask_len);
+
+/* Host-side helper: the jobs of a table grouped by read length (stable).  order[k] = the job that comes k-th (n_jobs entries); the read letters,
+ * read_off_out (n_jobs + 1) and the per-job arrays in that order; mask_len / mask_len_out may be NULL.  The windows are not touched.  A batch of mixed
+ * lengths that stays resident is cut into stream slices after this (a slice then holds one or two length classes: config 4 58 -> 65 M alignments/s);
+ * results come back in the grouped order, order[] takes them home. */
+int ipx_group_by_length(const int8_t *reads, const int64_t *read_off, const int32_t *ref_id, const uint8_t *gap_open, const uint8_t *gap_ext,
+                        const int32_t *mask_len, int64_t n_jobs, uint32_t *order, int8_t *reads_out, int64_t *read_off_out, int32_t *ref_id_out,
+                        uint8_t *gap_open_out, uint8_t *gap_ext_out, int32_t *mask_len_out);
 /* host-side helper: FNV-1a (32 bit) of every job's BAM-encoded CIGAR ops, 2166136261 for a job without CIGAR (whole batches are
  * compared op for op with the reference through these, and record digests are built on them) */
 void ipx_cigar_hashes(const ipx_result *rec, const uint32_t *cigar_pool, int64_t n, uint32_t *out);

@@ -37,7 +37,7 @@ EXPORTS = [
     "ipx_run", "ipx_sync", "ipx_download", "ipx_download_async", "ipx_wait", "ipx_set_async_io", "ipx_pin_host",
     "ipx_unpin_host", "ipx_align_batch", "ipx_set_profiling",
     "ipx_num_kernel_classes", "ipx_kernel_class_name", "ipx_kernel_times", "ipx_kernel_units", "ipx_last_run_ms", "ipx_debug_tb_counts", "ipx_debug_reruns",
-    "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars", "ipx_cigar_hashes", "ipx_record_digest", "ipx_concat_sizes", "ipx_concat_tables",
+    "ipx_synth_window", "ipx_synth_reads", "ipx_synth_mixed", "ipx_format_cigars", "ipx_cigar_hashes", "ipx_record_digest", "ipx_concat_sizes", "ipx_concat_tables", "ipx_group_by_length",
 ]
 
 
@@ -210,6 +210,8 @@ def load(path):
     L.ipx_concat_sizes.argtypes = [vp, i64, vp]
     L.ipx_concat_tables.restype = C.c_int
     L.ipx_concat_tables.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ipx_group_by_length.restype = C.c_int
+    L.ipx_group_by_length.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     L.ipx_synth_reads.restype = C.c_uint64
     L.ipx_synth_reads.argtypes = [C.c_uint64, vp, i32, vp, i64, i32]
     L.ipx_synth_mixed.restype = i64

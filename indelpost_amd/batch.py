@@ -150,6 +150,23 @@ class JobTable:
         out.table_jobs = desc[8::10].copy()                         # jobs per input table (BatchResult.split takes it)
         return out
 
+    def grouped_by_length(self):
+        """(table, order): the same jobs GROUPED BY READ LENGTH (stable), order[k] = the job of this table that comes k-th.  The library's
+        copy (ipx_group_by_length: counting sort + one memcpy per job, several threads; ~10 ms per million jobs).  Windows are shared, not copied."""
+        L = _lib.lib()
+        n = self.n_jobs
+        order = np.empty(n, np.uint32)
+        reads, read_off = np.empty(len(self.reads), np.int8), np.empty(n + 1, np.int64)
+        ref_id, go, ge = np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        mask = None if self.mask_len is None else np.empty(n, np.int32)
+        src = [np.ascontiguousarray(a) for a in (self.reads, self.read_off, self.ref_id, self.gap_open, self.gap_ext)]
+        rc = L.ipx_group_by_length(src[0].ctypes.data, src[1].ctypes.data, src[2].ctypes.data, src[3].ctypes.data, src[4].ctypes.data,
+                                   None if mask is None else np.ascontiguousarray(self.mask_len).ctypes.data, n, order.ctypes.data, reads.ctypes.data,
+                                   read_off.ctypes.data, ref_id.ctypes.data, go.ctypes.data, ge.ctypes.data, None if mask is None else mask.ctypes.data)
+        if rc != 0:
+            raise IpxError("ipx_group_by_length: %s" % L.ipx_last_error().decode())
+        return JobTable(reads, read_off, self.refs, self.ref_off, ref_id, go, ge, mask), order
+
     def shard(self, lo, hi):
         """Contiguous job range [lo, hi) with only the windows it references."""
         rid = self.ref_id[lo:hi]
@@ -539,6 +556,8 @@ class MultiStreamAligner:
         self._out = None             # pinned (records, cigar pool) pairs, used in alternation by collect(): see pin_host
         self._out_turn = 0
         self._staging = None         # page-locked input staging of loci_staging (a LociStaging)
+        self.group_by_length = "auto"   # upload(): group a big batch of mixed read lengths by length before cutting it (True / False / "auto")
+        self._order = None           # ... the order that takes its results home (download())
         self._out_pinned, self._out_loci = [], False     # the output pairs ensure_outputs made
 
     def close(self):
@@ -634,9 +653,29 @@ class MultiStreamAligner:
         for p in self.parts:
             p.set_routing(flags)
 
+    def _worth_grouping(self, jobs):
+        """a big batch of SEVERAL length classes (read length / 8, the 16-bit passes' class), each with a tenth of the jobs at least"""
+        if self.group_by_length != "auto":
+            return bool(self.group_by_length)
+        if jobs.n_jobs < 400000 or len(self.parts) < 2:
+            return False
+        cls = np.bincount((np.diff(jobs.read_off) + 7) >> 3)
+        return int((cls >= jobs.n_jobs // 10).sum()) >= 2
+
     def upload(self, jobs):
+        """Make `jobs` resident: cut into one slice per stream and copied in.  A batch of mixed read lengths that is uploaded to be run (a batch
+        that STAYS: run() many times, or upload / run / download of a large table) is first grouped by read length (JobTable.grouped_by_length;
+        group_by_length = "auto" / True / False) and cut by WORK: a slice then holds one or two length classes, its launches are four times as
+        large and half as many, and the classes are large enough for the banded reverse pass -- config 4: 58 -> 65 M aln/s.  download() returns
+        the records in the caller's job order either way.  (submit() / align() -- a batch that passes through once -- do not: grouping a million
+        jobs costs the host more than it saves the GPU.)"""
+        self._order = None
+        by_cells = self.balance_by_cells
+        if self._worth_grouping(jobs):
+            jobs, self._order = jobs.grouped_by_length()
+            by_cells = True
         k = max(1, min(len(self.parts), jobs.n_jobs // self.min_jobs_per_stream))   # small batches: one stream
-        b = shard_bounds(jobs.n_jobs, k, jobs if self.balance_by_cells else None)
+        b = shard_bounds(jobs.n_jobs, k, jobs if by_cells else None)
         self._active = self.parts[:k]
         self._slices = [jobs.shard(b[i], b[i + 1]) for i in range(k)]
         for p, j in zip(self._active, self._slices):
@@ -654,6 +693,15 @@ class MultiStreamAligner:
         """Gather the slices' results.  Every slice downloads straight into its range of ONE record array and its own
         region of ONE cigar pool (offsets rebased in place), so nothing is concatenated; the pool may have unused gaps
         between the regions."""
+        if self._order is not None:                                 # the batch was grouped by read length on its way in: back to the caller's order
+            order, self._order = self._order, None
+            try:
+                got = self.download(cigar_ops_per_job)
+            finally:
+                self._order = order
+            rec = np.empty_like(got.records)
+            rec[order] = got.records
+            return BatchResult(rec, got.cigar_pool)
         if not hasattr(self._active[0], "download_into"):          # test back-ends
             return merge_results([p.download(cigar_ops_per_job) for p in self._active])
         ns = [p._n_jobs for p in self._active]
@@ -683,6 +731,7 @@ class MultiStreamAligner:
         b = shard_bounds(jobs.n_jobs, k, jobs if self.balance_by_cells else None)
         self._active = self.parts[:k]
         self._submitted = jobs
+        self._order = None
 
         def one(i):                                                # cut, enqueue the copies of and launch slice i
             j = jobs.shard(b[i], b[i + 1])

@@ -407,3 +407,44 @@ def test_library_concat_handles_views_masks_and_empty_tables(hip_lib):
     bad = JobTable(parts[0].reads, parts[0].read_off, parts[0].refs, parts[0].ref_off, parts[0].ref_id + 50, parts[0].gap_open, parts[0].gap_ext)
     with pytest.raises(ip.IpxError):
         JobTable.concat([parts[3], bad])
+
+
+def test_grouping_by_read_length(emu):
+    """JobTable.grouped_by_length (the library's ipx_group_by_length): a stable counting sort of the jobs by read length -- reads, offsets and the
+    per-job arrays in the new order, windows shared; and MultiStreamAligner.upload() with group_by_length on: the slices hold the grouped jobs,
+    download() hands the records back in the caller's order, equal to the ungrouped run"""
+    rng = np.random.default_rng(8)
+    wins = [rng.integers(0, 4, int(n)).astype(np.int8) for n in (90, 140, 200)]
+    reads, rid, go, ge, mask = [], [], [], [], []
+    for i in range(60):
+        ln = int(rng.choice([30, 30, 47, 64, 64, 64, 100, 0]))
+        w = int(rng.integers(0, 3))
+        st = int(rng.integers(0, max(1, len(wins[w]) - ln))) if ln else 0
+        r = wins[w][st:st + ln].copy()
+        if ln > 10:
+            r[int(rng.integers(0, ln))] ^= 1
+        reads.append(r); rid.append(w); go.append(int(rng.integers(2, 6))); ge.append(int(rng.integers(0, 2))); mask.append(int(rng.integers(15, 40)))
+    jobs = JobTable.from_sequences(reads, wins, rid, go, ge, encoded=True)
+    jobs.mask_len = np.asarray(mask, np.int32)
+    g, order = jobs.grouped_by_length()
+    lens = np.diff(jobs.read_off)
+    assert order.tolist() == np.argsort(lens, kind="stable").tolist()
+    assert np.diff(g.read_off).tolist() == sorted(lens.tolist()) and g.refs is jobs.refs
+    for k, j in enumerate(order.tolist()):
+        assert g.reads[g.read_off[k]:g.read_off[k + 1]].tobytes() == jobs.reads[jobs.read_off[j]:jobs.read_off[j + 1]].tobytes()
+        assert (g.ref_id[k], g.gap_open[k], g.gap_ext[k], g.mask_len[k]) == (jobs.ref_id[j], jobs.gap_open[j], jobs.gap_ext[j], jobs.mask_len[j])
+    jobs.mask_len = None
+    plain = ip.MultiStreamAligner(0, 3, 2, streams=3, aligner_cls=emu)
+    plain.min_jobs_per_stream = 10
+    plain.group_by_length = False
+    plain.upload(jobs); plain.run(); plain.sync()
+    want = plain.download()
+    m = ip.MultiStreamAligner(0, 3, 2, streams=3, aligner_cls=emu)
+    m.min_jobs_per_stream = 10
+    assert not m._worth_grouping(jobs)                                 # ("auto": a small batch is left as it is)
+    m.group_by_length = True
+    m.upload(jobs); m.run(); m.sync()
+    assert m._order is not None and [int(np.diff(s_.read_off).max(initial=0)) for s_ in m._slices] == sorted(int(np.diff(s_.read_off).max(initial=0)) for s_ in m._slices)
+    got = m.download()
+    assert all(got.as_dict(i) == want.as_dict(i) for i in range(jobs.n_jobs))
+    assert all(m.align(jobs).as_dict(i) == want.as_dict(i) for i in range(jobs.n_jobs)) and m._order is None      # (a batch that passes through: as given)
