@@ -816,14 +816,15 @@ def device_count():
 
 def shard_bounds(n_jobs, n_shards, jobs=None):
     """Contiguous job ranges, shard k owns [b[k], b[k+1]).  Without a table: near-equal job COUNTS.  With the job table: near-equal
-    WORK -- cumulative read length x window length, the cell count of the forward pass -- so that a table sorted by read length (the
-    length-bucketed table of SURVEY.md 8e) does not hand the last shard three times the first one's cells."""
+    WORK -- cumulative (read length + 40) x (window length + 60): the cell count of the forward pass plus what a job costs whatever its size
+    (proofs, traceback, the wavefront's lead-in: config 4 grouped by length, 64.9 -> 66.1 M aln/s against plain cells) -- so that a table
+    sorted by read length (the length-bucketed table of SURVEY.md 8e) does not hand the last shard three times the first one's cells."""
     if jobs is None or n_shards <= 1 or n_jobs == 0:
         return [n_jobs * k // n_shards for k in range(n_shards + 1)]
     cache = jobs.__dict__.setdefault("_work_bounds", {})           # (a table's cuts are asked for again every step it is aligned)
     if n_shards in cache:
         return list(cache[n_shards])
-    cells = np.cumsum(np.diff(jobs.read_off).astype(np.float64) * np.diff(jobs.ref_off)[jobs.ref_id])
+    cells = np.cumsum((np.diff(jobs.read_off).astype(np.float64) + 40.0) * (np.diff(jobs.ref_off)[jobs.ref_id] + 60.0))
     cuts = np.searchsorted(cells, cells[-1] * np.arange(1, n_shards) / n_shards, side="left") + 1
     b = [0] + [int(min(max(c, 0), n_jobs)) for c in cuts] + [n_jobs]
     for k in range(1, len(b)):                                     # monotone (degenerate tables: empty shards are fine)

@@ -219,14 +219,15 @@ def test_synthetic_config_tables(hip_lib):
 
 
 def test_shard_bounds_by_work_balances_a_length_sorted_table():
-    """shard_bounds with the table cuts by cumulative read length x window length: on a table sorted by read length (SURVEY.md
-    8e's length-bucketed table) equal job COUNTS would give the last of 8 shards several times the first one's cells"""
+    """shard_bounds with the table cuts by cumulative work -- (read length + 40) x (window length + 60): the forward pass's cells plus what a
+    job costs whatever its size -- : on a table sorted by read length (SURVEY.md 8e's length-bucketed table) equal job COUNTS would give
+    the last of 8 shards several times the first one's work"""
     rng = np.random.default_rng(3)
     lens = np.sort(rng.choice([75, 100, 125, 150, 200, 250], 4000))
     wins = [rng.integers(0, 4, int(n)).astype(np.int8) for n in rng.integers(200, 601, 40)]
     rid = rng.integers(0, 40, 4000).astype(np.int32)
     jobs = JobTable.from_sequences([np.zeros(int(n), np.int8) for n in lens], wins, rid, 3, 1, encoded=True)
-    cells = np.diff(jobs.read_off) * np.diff(jobs.ref_off)[jobs.ref_id]
+    cells = (np.diff(jobs.read_off) + 40) * (np.diff(jobs.ref_off)[jobs.ref_id] + 60)
     for k in (2, 4, 8):
         b = shard_bounds(jobs.n_jobs, k, jobs)
         assert b[0] == 0 and b[-1] == jobs.n_jobs and all(x <= y for x, y in zip(b, b[1:]))
