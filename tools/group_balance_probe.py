@@ -10,22 +10,17 @@ orig = batch.shard_bounds
 
 def model(name):
     def bounds(n, k, jb=None):
-        if jb is None or k <= 1 or name == "cells":
+        if jb is None or k <= 1 or name == "product":
             return orig(n, k, jb)
+        a, b, pw = name
         L = np.diff(jb.read_off).astype(np.float64)
         Wd = (jb.ref_off[1:] - jb.ref_off[:-1])[jb.ref_id].astype(np.float64)
-        if name == "cells+fixed":
-            w = (L + 40) * (Wd + 60)
-        elif name == "rows8":
-            w = (8 * np.ceil(L / 8) + 22) * (Wd + 7) + 0.55 * (8 * np.ceil(L / 8) + 22) * (L + 30)
-        else:
-            w = np.ones_like(L)
+        w = (L + a) ** pw * (Wd + b)
         c = np.cumsum(w)
-        cuts = [0] + [int(np.searchsorted(c, c[-1] * i / k)) for i in range(1, k)] + [n]
-        return cuts
+        return [0] + [int(np.searchsorted(c, c[-1] * i / k)) for i in range(1, k)] + [n]
     return bounds
 
-for name in ("cells", "cells+fixed", "rows8"):
+for name in ("product", (40, 60, 0.85), (40, 60, 0.7), (80, 60, 0.7), (40, 200, 0.7), (40, 60, 0.5)):
     batch.shard_bounds = model(name)
     g = ip.MultiStreamAligner(0, 3, 2, streams=4)
     g.upload(jobs)
